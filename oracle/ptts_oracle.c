@@ -1,0 +1,1280 @@
+/*
+ * ptts_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ * See ptts_oracle.h for the role of this file.  Build: oracle/Makefile
+ * (gcc -O2 -ffp-contract=off: Go on amd64/GOAMD64=v1 never fuses a*b+c, so the
+ * compiler must not either; the only fused ops are the explicit fmaf() calls
+ * that restate VFMADD231PS/SS in dot_amd64.s).
+ *
+ * All arithmetic follows the reference operation for operation, including the
+ * float64 accumulations (LayerNorm mean/var, softmax exp/sum, erf, exp) and the
+ * AVX2 dot-product summation order (4 accumulators x 8 lanes, fold, 8-wide
+ * drain, scalar tail into lane 0, extract/add, two horizontal adds).
+ */
+#include "ptts_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* worker model: fork-join static chunking (tensor/runtime.go:46-76,
+ * ops/conv_runtime.go:36-61).  Results never depend on the worker count:
+ * every output element is produced by the same sequential code. */
+static int g_tensor_workers = 1; /* tensor/runtime.go:12-14 package default 1 */
+static int g_conv_workers   = 1;
+static int g_use_avx2       = 1; /* dot_amd64.go:9 useAVX2FMA on the reference's amd64 hosts */
+
+void po_set_workers(int tw, int cw) {
+    g_tensor_workers = tw < 1 ? 1 : tw;
+    g_conv_workers   = cw < 1 ? 1 : cw;
+}
+void po_set_use_avx2(int on) { g_use_avx2 = on ? 1 : 0; }
+
+typedef void (*range_fn)(int64_t lo, int64_t hi, void* ctx);
+
+static void parallel_for(int64_t n, int workers, range_fn fn, void* ctx) {
+    if (n <= 1 || workers <= 1) { fn(0, n, ctx); return; }
+    if (workers > n) workers = (int)n;
+    int64_t chunk = (n + workers - 1) / workers;
+    int64_t nchunks = (n + chunk - 1) / chunk;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) num_threads(workers)
+#endif
+    for (int64_t c = 0; c < nchunks; c++) {
+        int64_t lo = c * chunk, hi = lo + chunk;
+        if (hi > n) hi = n;
+        fn(lo, hi, ctx);
+    }
+}
+
+static void* xmalloc(size_t n) { void* p = malloc(n ? n : 1); if (!p) { fprintf(stderr, "oracle: oom\n"); abort(); } return p; }
+static float* fzeros(int64_t n) { float* p = (float*)calloc((size_t)(n > 0 ? n : 1), sizeof(float)); if (!p) { fprintf(stderr, "oracle: oom\n"); abort(); } return p; }
+
+/* ------------------------------------------------------------------------- */
+/* dot / axpy */
+
+float po_dot_generic(const float* a, const float* b, int64_t n) { /* dot.go:11-39 */
+    if (n == 0) return 0.0f;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int64_t i = 0;
+    for (; i + 7 < n; i += 8) {
+        s0 += a[i + 0] * b[i + 0];
+        s1 += a[i + 1] * b[i + 1];
+        s2 += a[i + 2] * b[i + 2];
+        s3 += a[i + 3] * b[i + 3];
+        s0 += a[i + 4] * b[i + 4];
+        s1 += a[i + 5] * b[i + 5];
+        s2 += a[i + 6] * b[i + 6];
+        s3 += a[i + 7] * b[i + 7];
+    }
+    for (; i < n; i++) s0 += a[i] * b[i];
+    return s0 + s1 + s2 + s3;
+}
+
+/* dot_amd64.s:34-116 restated lane by lane with fmaf (== VFMADD231PS per lane). */
+float po_dot_avx2_order(const float* a, const float* b, int64_t n) {
+    float y0[8] = {0}, y1[8] = {0}, y2[8] = {0}, y3[8] = {0};
+    int64_t cx = n;
+    if (cx >= 32) {
+        do { /* loop32 */
+            for (int l = 0; l < 8; l++) y0[l] = fmaf(a[l],      b[l],      y0[l]);
+            for (int l = 0; l < 8; l++) y1[l] = fmaf(a[8 + l],  b[8 + l],  y1[l]);
+            for (int l = 0; l < 8; l++) y2[l] = fmaf(a[16 + l], b[16 + l], y2[l]);
+            for (int l = 0; l < 8; l++) y3[l] = fmaf(a[24 + l], b[24 + l], y3[l]);
+            a += 32; b += 32; cx -= 32;
+        } while (cx >= 32);
+        /* VADDPS Y1,Y0,Y0 ; VADDPS Y3,Y2,Y2 ; VADDPS Y2,Y0,Y0 */
+        for (int l = 0; l < 8; l++) y0[l] = y0[l] + y1[l];
+        for (int l = 0; l < 8; l++) y2[l] = y2[l] + y3[l];
+        for (int l = 0; l < 8; l++) y0[l] = y0[l] + y2[l];
+    }
+    while (cx >= 8) { /* loop8 */
+        for (int l = 0; l < 8; l++) y0[l] = fmaf(a[l], b[l], y0[l]);
+        a += 8; b += 8; cx -= 8;
+    }
+    while (cx > 0) { /* loop1: VFMADD231SS into lane 0 */
+        y0[0] = fmaf(a[0], b[0], y0[0]);
+        a++; b++; cx--;
+    }
+    /* VEXTRACTF128 $1 ; VADDPS X1,X0,X0 */
+    float x0[4];
+    for (int l = 0; l < 4; l++) x0[l] = y0[l] + y0[4 + l];
+    /* VHADDPS X0,X0,X0 twice */
+    float h0 = x0[0] + x0[1], h1 = x0[2] + x0[3];
+    return h0 + h1;
+}
+
+static inline float dot_f32(const float* a, const float* b, int64_t n) { /* dot_amd64.go:13-19 */
+    if (g_use_avx2 && n >= 8) return po_dot_avx2_order(a, b, n);
+    return po_dot_generic(a, b, n);
+}
+float po_dot(const float* a, const float* b, int64_t n) { return dot_f32(a, b, n); }
+
+/* axpy.go:5-19, axpy_amd64.go, axpy_amd64.s: VMULPS then VADDPS -- unfused, so
+ * the AVX2 and generic paths give identical bits. */
+void po_axpy(float* dst, int64_t ndst, float alpha, const float* src, int64_t nsrc) {
+    int64_t n = ndst < nsrc ? ndst : nsrc;
+    if (n == 0 || alpha == 0.0f) return;
+    for (int64_t i = 0; i < n; i++) { float p = alpha * src[i]; dst[i] = dst[i] + p; }
+}
+
+/* ------------------------------------------------------------------------- */
+/* tensor/nn_ops.go */
+
+int po_softmax_lastdim(const float* x, int64_t outer, int64_t d, float* y) { /* nn_ops.go:15-76 (inner==1) */
+    if (d <= 0) return -1;
+    for (int64_t o = 0; o < outer; o++) {
+        const float* s = x + o * d; float* t = y + o * d;
+        float maxv = -INFINITY;
+        for (int64_t k = 0; k < d; k++) if (s[k] > maxv) maxv = s[k];
+        double sum = 0;
+        for (int64_t k = 0; k < d; k++) { double e = exp((double)(s[k] - maxv)); t[k] = (float)e; sum += e; }
+        if (sum == 0) return -2;
+        float inv = (float)(1.0 / sum);
+        for (int64_t k = 0; k < d; k++) t[k] *= inv;
+    }
+    return 0;
+}
+
+typedef struct { const float* x; const float* w; const float* b; float eps; int64_t d; float* y; } ln_ctx;
+static void ln_rows(int64_t lo, int64_t hi, void* vc) { /* linear.go:289-317 */
+    ln_ctx* c = (ln_ctx*)vc; int64_t dd = c->d;
+    for (int64_t o = lo; o < hi; o++) {
+        const float* src = c->x + o * dd; float* dst = c->y + o * dd;
+        double mean = 0;
+        for (int64_t i = 0; i < dd; i++) mean += (double)src[i];
+        mean /= (double)dd;
+        double var = 0;
+        for (int64_t i = 0; i < dd; i++) { double delta = (double)src[i] - mean; var += delta * delta; }
+        var /= (double)dd;
+        float inv_std = (float)(1.0 / sqrt(var + (double)c->eps));
+        float meanf = (float)mean;
+        for (int64_t i = 0; i < dd; i++) {
+            float n = (src[i] - meanf) * inv_std;
+            if (c->w) n = n * c->w[i];
+            if (c->b) n = n + c->b[i];
+            dst[i] = n;
+        }
+    }
+}
+int po_layernorm(const float* x, const float* w, const float* b, float eps, int64_t outer, int64_t d, float* y) {
+    if (eps <= 0 || d <= 0) return -1;
+    ln_ctx c = { x, w, b, eps, d, y };
+    /* linear.go:319-326 threshold */
+    if (g_tensor_workers > 1 && outer > 1 && outer * d >= ((int64_t)1 << 17)) parallel_for(outer, g_tensor_workers, ln_rows, &c);
+    else ln_rows(0, outer, &c);
+    return 0;
+}
+
+typedef struct { const float* x; const float* w; const float* bias; int64_t in, out; float* y; } lin_ctx;
+static void lin_batch(int64_t lo, int64_t hi, void* vc) { /* linear.go:143-155 */
+    lin_ctx* c = (lin_ctx*)vc;
+    for (int64_t bi = lo; bi < hi; bi++) {
+        const float* xs = c->x + bi * c->in; float* yb = c->y + bi * c->out;
+        for (int64_t o = 0; o < c->out; o++) {
+            float sum = dot_f32(xs, c->w + o * c->in, c->in);
+            if (c->bias) sum += c->bias[o];
+            yb[o] = sum;
+        }
+    }
+}
+static void lin_single(int64_t lo, int64_t hi, void* vc) { /* linear.go:157-166 */
+    lin_ctx* c = (lin_ctx*)vc;
+    for (int64_t o = lo; o < hi; o++) {
+        float sum = dot_f32(c->x, c->w + o * c->in, c->in);
+        if (c->bias) sum += c->bias[o];
+        c->y[o] = sum;
+    }
+}
+int po_linear(const float* x, const float* w, const float* bias, int64_t batch, int64_t in, int64_t out, float* y) {
+    lin_ctx c = { x, w, bias, in, out, y };
+    int64_t fmas = batch * out * in; int wk = g_tensor_workers; /* linear.go:168-179 */
+    if (wk > 1 && fmas >= ((int64_t)1 << 18) && batch > 1) parallel_for(batch, wk, lin_batch, &c);
+    else if (wk > 1 && fmas >= ((int64_t)1 << 18) && batch == 1 && out > 1) parallel_for(out, wk, lin_single, &c);
+    else lin_batch(0, batch, &c);
+    return 0;
+}
+
+int po_matmul2d(const float* a, const float* b, int64_t m, int64_t k, int64_t n, float* c) { /* nn_ops.go:228-249 */
+    for (int64_t i = 0; i < m; i++)
+        for (int64_t j = 0; j < n; j++) {
+            float sum = 0;
+            for (int64_t kk = 0; kk < k; kk++) sum += a[i * k + kk] * b[kk * n + j];
+            c[i * n + j] = sum;
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* native/tensor_util.go elementwise */
+
+void po_gelu_erf(float* x, int64_t n) { /* :84-94 */
+    for (int64_t i = 0; i < n; i++) { double fv = (double)x[i]; x[i] = (float)(0.5 * fv * (1 + erf(fv / M_SQRT2))); }
+}
+void po_silu(float* x, int64_t n) { /* :73-82 */
+    for (int64_t i = 0; i < n; i++) { float v = x[i]; x[i] = v / (1 + (float)exp((double)(-v))); }
+}
+void po_elu(float* x, int64_t n) { /* :119-128 */
+    for (int64_t i = 0; i < n; i++) { float v = x[i]; if (v <= 0) x[i] = (float)exp((double)v) - 1; }
+}
+int po_rmsnorm_alpha(float* x, const float* alpha, float eps, int64_t outer, int64_t d) { /* :273-326 */
+    if (d <= 0) return -1;
+    for (int64_t i = 0; i < outer; i++) {
+        float* r = x + i * d;
+        double mean = 0;
+        for (int64_t j = 0; j < d; j++) mean += (double)r[j];
+        mean /= (double)d;
+        double var = 0;
+        for (int64_t j = 0; j < d; j++) { double diff = (double)r[j] - mean; var += diff * diff; }
+        if (d > 1) var /= (double)(d - 1);
+        float inv = (float)(1.0 / sqrt(var + (double)eps));
+        for (int64_t j = 0; j < d; j++) r[j] = r[j] * inv * alpha[j];
+    }
+    return 0;
+}
+void po_replace_nan(float* x, int64_t n, const float* vec, int64_t d) { /* :242-271 */
+    for (int64_t i = 0; i < n; i++) if (isnan(x[i])) x[i] = vec[i % d];
+}
+int po_denorm_latent_to_bct(const float* latent, const float* std, const float* mean,
+                            int64_t b, int64_t t, int64_t d, float* out) { /* model.go:349-407 */
+    for (int64_t bi = 0; bi < b; bi++)
+        for (int64_t ti = 0; ti < t; ti++)
+            for (int64_t di = 0; di < d; di++)
+                out[bi * d * t + di * t + ti] = latent[bi * t * d + ti * d + di] * std[di] + mean[di];
+    return 0;
+}
+int po_split_voice_kv(const float* cache, int64_t b, int64_t steps, int64_t heads, int64_t hd, float* k, float* v) {
+    /* flow_transformer.go:598-631: [2,B,T,H,D] -> k,v [B,H,T,D] */
+    for (int64_t batch = 0; batch < b; batch++)
+        for (int64_t step = 0; step < steps; step++)
+            for (int64_t head = 0; head < heads; head++)
+                for (int64_t dim = 0; dim < hd; dim++) {
+                    int64_t dst = ((batch * heads + head) * steps + step) * hd + dim;
+                    int64_t ks = ((((0 * b + batch) * steps + step) * heads + head) * hd + dim);
+                    int64_t vs = ((((1 * b + batch) * steps + step) * heads + head) * hd + dim);
+                    k[dst] = cache[ks]; v[dst] = cache[vs];
+                }
+    return 0;
+}
+void po_gaussian_zero_or_passthrough(void) {}
+
+/* ------------------------------------------------------------------------- */
+/* ops/rope.go:81-105 */
+int po_rope(float* x, const float* cos_t, const float* sin_t, int64_t prefix, int64_t seq, int64_t dim, int64_t pos) {
+    if (pos < 0 || (dim & 1)) return -1;
+    int64_t half = dim / 2;
+    for (int64_t pre = 0; pre < prefix; pre++) {
+        int64_t pbase = pre * seq * dim;
+        for (int64_t t = 0; t < seq; t++) {
+            int64_t tb = (pos + t) * half, xb = pbase + t * dim;
+            for (int64_t j = 0; j < half; j++) {
+                float a = x[xb + 2 * j], b = x[xb + 2 * j + 1];
+                float c = cos_t[tb + j], s = sin_t[tb + j];
+                float ac = a * c, bs = b * s, as = a * s, bc = b * c;
+                x[xb + 2 * j]     = ac - bs;
+                x[xb + 2 * j + 1] = as + bc;
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ops/attention.go */
+
+static inline int mask_allows(int64_t pq, int64_t pk, int64_t context) { /* attention.go:473-484 */
+    if (pk < 0) return 0;
+    int64_t delta = pq - pk;
+    if (delta < 0) return 0;
+    return context < 0 || delta < context;
+}
+
+typedef struct {
+    const float *q, *k, *v; float* out;
+    int64_t b, h, tq, tk, d, dv;
+    int mode; /* 0: causal/offset (attention4D), 1: positions */
+    int causal; int64_t offset;
+    const int64_t *posq, *posk; int64_t context;
+    int failed;
+} attn_ctx;
+
+static void attn_jobs(int64_t lo, int64_t hi, void* vc) { /* attention.go:208-293 / 375-457 */
+    attn_ctx* c = (attn_ctx*)vc;
+    float* scores = (float*)xmalloc(sizeof(float) * (size_t)c->tk);
+    float scale = (float)(1.0 / sqrt((double)c->d));
+    int64_t jobs_per_head = c->tq, jobs_per_batch = c->h * c->tq;
+    for (int64_t job = lo; job < hi; job++) {
+        if (c->failed) break;
+        int64_t bi = job / jobs_per_batch, rem = job % jobs_per_batch;
+        int64_t hd = rem / jobs_per_head, qi = rem % jobs_per_head;
+        const float* qrow = c->q + ((bi * c->h + hd) * c->tq + qi) * c->d;
+        const float* kb = c->k + (bi * c->h + hd) * c->tk * c->d;
+        const float* vb = c->v + (bi * c->h + hd) * c->tk * c->dv;
+        float* orow = c->out + ((bi * c->h + hd) * c->tq + qi) * c->dv;
+        float maxv = -INFINITY;
+        int64_t maxkey = qi + c->offset;
+        for (int64_t ki = 0; ki < c->tk; ki++) {
+            int allowed = c->mode == 1 ? mask_allows(c->posq[qi], c->posk[ki], c->context)
+                                       : !(c->causal && ki > maxkey);
+            if (!allowed) { scores[ki] = -INFINITY; continue; }
+            float s = dot_f32(qrow, kb + ki * c->d, c->d) * scale;
+            scores[ki] = s;
+            if (s > maxv) maxv = s;
+        }
+        for (int64_t i = 0; i < c->dv; i++) orow[i] = 0;
+        if (isinf(maxv) && maxv < 0) continue;
+        double sum = 0;
+        for (int64_t ki = 0; ki < c->tk; ki++) {
+            float s = scores[ki];
+            if (isinf(s) && s < 0) { scores[ki] = 0; continue; }
+            double e = exp((double)(s - maxv));
+            scores[ki] = (float)e; sum += e;
+        }
+        if (sum == 0 || isnan(sum)) { c->failed = 1; break; }
+        float inv = (float)(1.0 / sum);
+        for (int64_t ki = 0; ki < c->tk; ki++) {
+            float w = scores[ki] * inv;
+            if (w == 0) continue;
+            po_axpy(orow, c->dv, w, vb + ki * c->dv, c->dv);
+        }
+    }
+    free(scores);
+}
+
+int po_attention(const float* q, const float* k, const float* v, int64_t b, int64_t h, int64_t tq, int64_t tk,
+                 int64_t d, int64_t dv, int causal, int64_t offset, float* out) {
+    if (b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || d <= 0 || dv <= 0) return -1;
+    attn_ctx c = { q, k, v, out, b, h, tq, tk, d, dv, 0, causal, offset, NULL, NULL, -1, 0 };
+    int64_t jobs = b * h * tq, work = jobs * tk * (d + dv); /* attention.go:188-191 */
+    if (g_tensor_workers > 1 && jobs > 1 && work >= ((int64_t)1 << 20)) parallel_for(jobs, g_tensor_workers, attn_jobs, &c);
+    else attn_jobs(0, jobs, &c);
+    return c.failed ? -2 : 0;
+}
+int po_attention_positions(const float* q, const float* k, const float* v, int64_t b, int64_t h, int64_t tq, int64_t tk,
+                 int64_t d, int64_t dv, const int64_t* posq, const int64_t* posk, int64_t context, float* out) {
+    if (b <= 0 || h <= 0 || tq <= 0 || tk <= 0 || d <= 0 || dv <= 0) return -1;
+    attn_ctx c = { q, k, v, out, b, h, tq, tk, d, dv, 1, 0, 0, posq, posk, context, 0 };
+    int64_t jobs = b * h * tq; /* attention.go:459-464 */
+    if (g_tensor_workers > 1 && jobs > 1) parallel_for(jobs, g_tensor_workers, attn_jobs, &c);
+    else attn_jobs(0, jobs, &c);
+    return c.failed ? -2 : 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ops/conv1d.go */
+
+int64_t po_conv1d_outlen(int64_t len, int64_t k, int64_t stride, int64_t lpad, int64_t rpad, int64_t dil) {
+    return (len + lpad + rpad - dil * (k - 1) - 1) / stride + 1; /* conv1d.go:185 */
+}
+
+typedef struct { const float *kernel, *bias, *imcol; float* out; int64_t patch, out_len; } conv_ctx;
+static void conv_oc(int64_t lo, int64_t hi, void* vc) { /* conv1d.go:67-81 */
+    conv_ctx* c = (conv_ctx*)vc;
+    for (int64_t oc = lo; oc < hi; oc++) {
+        const float* krow = c->kernel + oc * c->patch;
+        float bv = c->bias ? c->bias[oc] : 0.0f;
+        float* o = c->out + oc * c->out_len;
+        for (int64_t ox = 0; ox < c->out_len; ox++) o[ox] = dot_f32(krow, c->imcol + ox * c->patch, c->patch) + bv;
+    }
+}
+
+int po_conv1d(const float* in, const float* w, const float* bias, int64_t batch, int64_t in_ch, int64_t len,
+              int64_t out_ch, int64_t k, int64_t stride, int64_t lpad, int64_t rpad, int64_t dil, int64_t groups,
+              float* out) {
+    if (stride <= 0 || dil <= 0 || groups <= 0) return -1;
+    if (in_ch % groups || out_ch % groups) return -1;
+    int64_t out_len = po_conv1d_outlen(len, k, stride, lpad, rpad, dil);
+    if (out_len <= 0) return -2;
+    if (groups == 1) { /* conv1DFastGroups1 conv1d.go:20-83 */
+        int64_t patch = in_ch * k;
+        float* imcol = fzeros(out_len * patch);
+        for (int64_t b = 0; b < batch; b++) {
+            if (b > 0) memset(imcol, 0, sizeof(float) * (size_t)(out_len * patch));
+            for (int64_t ic = 0; ic < in_ch; ic++) {
+                const float* ib = in + (b * in_ch + ic) * len;
+                for (int64_t kx = 0; kx < k; kx++) {
+                    int64_t col = ic * k + kx;
+                    for (int64_t ox = 0; ox < out_len; ox++) {
+                        int64_t ip = ox * stride - lpad + kx * dil;
+                        if (ip >= 0 && ip < len) imcol[ox * patch + col] = ib[ip];
+                    }
+                }
+            }
+            conv_ctx c = { w, bias, imcol, out + b * out_ch * out_len, patch, out_len };
+            parallel_for(out_ch, g_conv_workers, conv_oc, &c);
+        }
+        free(imcol);
+        return 0;
+    }
+    /* conv1DGrouped conv1d.go:203-238 */
+    int64_t ipg = in_ch / groups, opg = out_ch / groups, kin = ipg;
+    for (int64_t b = 0; b < batch; b++)
+        for (int64_t oc = 0; oc < out_ch; oc++) {
+            int64_t g = oc / opg, in_start = g * ipg;
+            for (int64_t ox = 0; ox < out_len; ox++) {
+                float sum = bias ? bias[oc] : 0.0f;
+                for (int64_t ic = 0; ic < ipg; ic++)
+                    for (int64_t kx = 0; kx < k; kx++) {
+                        int64_t ip = ox * stride - lpad + kx * dil;
+                        if (ip < 0 || ip >= len) continue;
+                        sum += in[(b * in_ch + in_start + ic) * len + ip] * w[(oc * kin + ic) * k + kx];
+                    }
+                out[(b * out_ch + oc) * out_len + ox] = sum;
+            }
+        }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ops/convtranspose1d.go */
+
+int64_t po_convtr1d_outlen(int64_t len, int64_t k, int64_t stride, int64_t pad, int64_t outpad, int64_t dil, int64_t rt) {
+    return (len - 1) * stride - 2 * pad + dil * (k - 1) + outpad + 1 - rt; /* :309-315 */
+}
+void po_repack_convtr_kernel(const float* w, int64_t in_ch, int64_t out_ch, int64_t k, float* out) { /* :16-33 */
+    for (int64_t ic = 0; ic < in_ch; ic++)
+        for (int64_t oc = 0; oc < out_ch; oc++)
+            for (int64_t kx = 0; kx < k; kx++)
+                out[(kx * out_ch + oc) * in_ch + ic] = w[(ic * out_ch + oc) * k + kx];
+}
+
+typedef struct {
+    const float *kernel_t, *input_t, *bias; float* out;
+    int64_t in_ch, in_len, out_ch, out_len, k, stride, pad, dil;
+} ctr_ctx;
+static void ctr_oc(int64_t lo, int64_t hi, void* vc) { /* :121-146 */
+    ctr_ctx* c = (ctr_ctx*)vc;
+    for (int64_t oc = lo; oc < hi; oc++) {
+        float* orow = c->out + oc * c->out_len;
+        for (int64_t kx = 0; kx < c->k; kx++) {
+            const float* krow = c->kernel_t + (kx * c->out_ch + oc) * c->in_ch;
+            for (int64_t ix = 0; ix < c->in_len; ix++) {
+                int64_t op = ix * c->stride - c->pad + kx * c->dil;
+                if (op < 0 || op >= c->out_len) continue;
+                orow[op] += dot_f32(krow, c->input_t + ix * c->in_ch, c->in_ch);
+            }
+        }
+        if (c->bias) { float bv = c->bias[oc]; for (int64_t i = 0; i < c->out_len; i++) orow[i] += bv; }
+    }
+}
+
+int po_convtr1d(const float* in, const float* w, const float* bias, int64_t batch, int64_t in_ch, int64_t len,
+                int64_t opg, int64_t k, int64_t stride, int64_t pad, int64_t outpad, int64_t dil, int64_t groups,
+                int64_t right_trim, float* out) {
+    if (stride <= 0 || dil <= 0 || groups <= 0) return -1;
+    if (outpad < 0 || outpad >= stride) return -1;
+    if (in_ch % groups) return -1;
+    if (right_trim < 0) return -1;
+    int64_t out_ch = opg * groups, ipg = in_ch / groups;
+    int64_t out_len = po_convtr1d_outlen(len, k, stride, pad, outpad, dil, right_trim);
+    if (out_len <= 0) return -2;
+    memset(out, 0, sizeof(float) * (size_t)(batch * out_ch * out_len));
+    if (groups == 1) { /* convTranspose1DGroups1 :73-148 */
+        float* kt = (float*)xmalloc(sizeof(float) * (size_t)(k * out_ch * in_ch));
+        po_repack_convtr_kernel(w, in_ch, out_ch, k, kt);
+        float* it = fzeros(len * in_ch);
+        for (int64_t b = 0; b < batch; b++) {
+            for (int64_t ic = 0; ic < in_ch; ic++) {
+                const float* src = in + (b * in_ch + ic) * len;
+                for (int64_t ix = 0; ix < len; ix++) it[ix * in_ch + ic] = src[ix];
+            }
+            ctr_ctx c = { kt, it, bias, out + b * out_ch * out_len, in_ch, len, out_ch, out_len, k, stride, pad, dil };
+            parallel_for(out_ch, g_conv_workers, ctr_oc, &c);
+        }
+        free(kt); free(it);
+        return 0;
+    }
+    if (groups == in_ch) { /* convTranspose1DFastDepthwise :154-202 */
+        for (int64_t b = 0; b < batch; b++) {
+            for (int64_t g = 0; g < in_ch; g++) {
+                const float* ib = in + (b * in_ch + g) * len;
+                for (int64_t ix = 0; ix < len; ix++) {
+                    float iv = ib[ix];
+                    if (iv == 0) continue;
+                    for (int64_t ocg = 0; ocg < opg; ocg++) {
+                        int64_t oc = g * opg + ocg;
+                        float* os = out + (b * out_ch + oc) * out_len;
+                        for (int64_t kx = 0; kx < k; kx++) {
+                            int64_t op = ix * stride - pad + kx * dil;
+                            if (op >= 0 && op < out_len) { float p = iv * w[oc * k + kx]; os[op] = os[op] + p; }
+                        }
+                    }
+                }
+            }
+            if (bias)
+                for (int64_t oc = 0; oc < out_ch; oc++) {
+                    float* os = out + (b * out_ch + oc) * out_len;
+                    for (int64_t i = 0; i < out_len; i++) os[i] += bias[oc];
+                }
+        }
+        return 0;
+    }
+    /* convTranspose1DGrouped :333-362 + addConvTransposeBias :364-377 */
+    for (int64_t b = 0; b < batch; b++)
+        for (int64_t ic = 0; ic < in_ch; ic++) {
+            int64_t g = ic / ipg, oc_base = g * opg;
+            for (int64_t ix = 0; ix < len; ix++) {
+                float iv = in[(b * in_ch + ic) * len + ix];
+                for (int64_t ocg = 0; ocg < opg; ocg++)
+                    for (int64_t kx = 0; kx < k; kx++) {
+                        int64_t op = ix * stride - pad + kx * dil;
+                        if (op < 0 || op >= out_len) continue;
+                        float p = iv * w[(ic * opg + ocg) * k + kx];
+                        float* o = &out[(b * out_ch + oc_base + ocg) * out_len + op];
+                        *o = *o + p;
+                    }
+            }
+        }
+    if (bias)
+        for (int64_t b = 0; b < batch; b++)
+            for (int64_t oc = 0; oc < out_ch; oc++)
+                for (int64_t ox = 0; ox < out_len; ox++) out[(b * out_ch + oc) * out_len + ox] += bias[oc];
+    return 0;
+}
+
+int po_mlp_silu(const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                int64_t batch, int64_t in, int64_t hid, int64_t out, float* y) { /* ops/mlp.go:11-32 */
+    float* h = fzeros(batch * hid);
+    po_linear(x, w1, b1, batch, in, hid, h);
+    po_silu(h, batch * hid);
+    po_linear(h, w2, b2, batch, hid, out, y);
+    free(h);
+    return 0;
+}
+
+/* ========================================================================= */
+/* Model (internal/native)                                                   */
+/* ========================================================================= */
+
+typedef struct { const float* w; const float* b; int64_t in, out; } lin_t;  /* linear.go:11-16 */
+typedef struct { const float* w; const float* b; float eps; int64_t d; } lnorm_t; /* linear.go:184-189 */
+typedef struct { const float* w; const float* b; int64_t out_ch, in_ch, k; } conv_t; /* mimi.go:36-42 */
+typedef struct { const float* w; const float* b; int64_t in_ch, opg, k, stride, groups; } convtr_t; /* mimi.go:78-84 */
+
+typedef struct { lnorm_t norm1, norm2; lin_t in_proj, out_proj, linear1, linear2; int64_t heads, head_dim; } flow_layer_t;
+typedef struct { const float* freqs; int64_t nfreq; lin_t l1, l2; const float* alpha; } tembed_t; /* flow_net.go:11-16 */
+typedef struct { lnorm_t in_ln; lin_t mlp0, mlp2, ada; } resblock_t; /* flow_net.go:85-90 */
+typedef struct {
+    lnorm_t norm1, norm2; lin_t in_proj, out_proj, linear1, linear2;
+    const float *ls1, *ls2; int64_t heads, head_dim, context;
+} mimi_layer_t; /* mimi.go:166-178 */
+typedef struct { conv_t conv1, conv2; } seanet_rb_t;
+
+#define PO_MAX_LAYERS 32
+#define PO_ROPE_SEQ   8192
+
+struct po_model {
+    /* owned copies of every tensor */
+    int32_t n; char** names; float** data; int64_t** shapes; int32_t* ranks;
+
+    /* flow_lm.go:30-43 */
+    const float* embed; int64_t n_bins, d_model;
+    int64_t n_layers; flow_layer_t layers[PO_MAX_LAYERS];
+    float *rope_cos, *rope_sin; int64_t head_dim;
+    const float *emb_std, *emb_mean, *bos_emb; int64_t ldim;
+    lin_t input_linear, out_eos; lnorm_t out_norm;
+    /* flow_net.go:242-248 */
+    tembed_t tembed[2]; lin_t cond_embed, input_proj;
+    int64_t n_res; resblock_t res[PO_MAX_LAYERS];
+    lin_t final_linear, final_ada; int64_t flow_dim;
+    /* mimi.go:528-544 */
+    conv_t quant; convtr_t upsample;
+    int64_t n_mimi_layers; mimi_layer_t mimi_layers[PO_MAX_LAYERS];
+    float *mimi_cos, *mimi_sin; int64_t mimi_dim;
+    conv_t init_conv, final_conv; convtr_t up[3]; seanet_rb_t rb[3];
+    /* model.go:169-174 */
+    float *proj_w, *proj_b; int64_t proj_in, proj_out;
+};
+
+static int find_tensor(const po_model* m, const char* name) {
+    for (int i = 0; i < m->n; i++) if (strcmp(m->names[i], name) == 0) return i;
+    return -1;
+}
+static int has_tensor(const po_model* m, const char* name) { return find_tensor(m, name) >= 0; }
+
+#define FAIL(...) do { if (err && errlen > 0) snprintf(err, (size_t)errlen, __VA_ARGS__); return -1; } while (0)
+
+static int get_t(const po_model* m, const char* name, int want_rank, const float** d, const int64_t** shape,
+                 char* err, int32_t errlen) {
+    int i = find_tensor(m, name);
+    if (i < 0) FAIL("safetensors: tensor \"%s\" not found", name);
+    if (want_rank > 0 && m->ranks[i] != want_rank) FAIL("native: tensor \"%s\" rank %d, want %d", name, m->ranks[i], want_rank);
+    *d = m->data[i]; *shape = m->shapes[i];
+    return 0;
+}
+
+static int load_linear(const po_model* m, const char* prefix, const char* name, int with_bias, lin_t* l,
+                       char* err, int32_t errlen) { /* linear.go:18-45 */
+    char key[512]; const int64_t* sh;
+    snprintf(key, sizeof key, "%s%s.weight", prefix, name);
+    if (get_t(m, key, 2, &l->w, &sh, err, errlen)) return -1;
+    l->out = sh[0]; l->in = sh[1]; l->b = NULL;
+    if (with_bias) {
+        snprintf(key, sizeof key, "%s%s.bias", prefix, name);
+        int i = find_tensor(m, key);
+        if (i >= 0) {
+            if (m->ranks[i] != 1 || m->shapes[i][0] != l->out) FAIL("native: linear \"%s\" bias shape incompatible", name);
+            l->b = m->data[i];
+        }
+    }
+    return 0;
+}
+static int load_lnorm(const po_model* m, const char* prefix, const char* name, float eps, lnorm_t* ln,
+                      char* err, int32_t errlen) { /* linear.go:191-207 */
+    char key[512]; const int64_t *s1, *s2;
+    snprintf(key, sizeof key, "%s%s.weight", prefix, name);
+    if (get_t(m, key, 1, &ln->w, &s1, err, errlen)) return -1;
+    snprintf(key, sizeof key, "%s%s.bias", prefix, name);
+    if (get_t(m, key, 1, &ln->b, &s2, err, errlen)) return -1;
+    if (s1[0] != s2[0]) FAIL("native: layernorm \"%s\" invalid shapes", name);
+    ln->eps = eps; ln->d = s1[0];
+    return 0;
+}
+static int load_conv(const po_model* m, const char* prefix, int with_bias, conv_t* c, char* err, int32_t errlen) { /* mimi.go:44-67 */
+    char key[512]; const int64_t* sh;
+    snprintf(key, sizeof key, "%s.weight", prefix);
+    if (get_t(m, key, 3, &c->w, &sh, err, errlen)) return -1;
+    c->out_ch = sh[0]; c->in_ch = sh[1]; c->k = sh[2]; c->b = NULL;
+    if (with_bias) { snprintf(key, sizeof key, "%s.bias", prefix); int i = find_tensor(m, key); if (i >= 0) c->b = m->data[i]; }
+    return 0;
+}
+static int load_convtr(const po_model* m, const char* prefix, int64_t stride, int64_t groups, int with_bias,
+                       convtr_t* c, char* err, int32_t errlen) { /* mimi.go:86-114 */
+    char key[512]; const int64_t* sh;
+    snprintf(key, sizeof key, "%s.weight", prefix);
+    if (get_t(m, key, 3, &c->w, &sh, err, errlen)) return -1;
+    c->in_ch = sh[0]; c->opg = sh[1]; c->k = sh[2]; c->stride = stride; c->groups = groups; c->b = NULL;
+    if (with_bias) { snprintf(key, sizeof key, "%s.bias", prefix); int i = find_tensor(m, key); if (i >= 0) c->b = m->data[i]; }
+    return 0;
+}
+
+static void build_rope(int64_t max_seq, int64_t head_dim, double max_period, float** cos_o, float** sin_o) {
+    /* flow_transformer.go:797-832 */
+    int64_t half = head_dim / 2;
+    double* inv = (double*)xmalloc(sizeof(double) * (size_t)half);
+    for (int64_t i = 0; i < half; i++) inv[i] = 1.0 / pow(max_period, (double)i / (double)half);
+    float* c = (float*)xmalloc(sizeof(float) * (size_t)(max_seq * half));
+    float* s = (float*)xmalloc(sizeof(float) * (size_t)(max_seq * half));
+    for (int64_t pos = 0; pos < max_seq; pos++)
+        for (int64_t i = 0; i < half; i++) {
+            double ang = (double)pos * inv[i];
+            c[pos * half + i] = (float)cos(ang); s[pos * half + i] = (float)sin(ang);
+        }
+    free(inv); *cos_o = c; *sin_o = s;
+}
+
+static int load_tembed(const po_model* m, const char* prefix, tembed_t* te, char* err, int32_t errlen) { /* flow_net.go:18-40 */
+    char key[512]; const int64_t* sh;
+    snprintf(key, sizeof key, "%sfreqs", prefix);
+    if (get_t(m, key, 0, &te->freqs, &sh, err, errlen)) return -1;
+    { int i = find_tensor(m, key); int64_t n = 1; for (int r = 0; r < m->ranks[i]; r++) n *= m->shapes[i][r]; te->nfreq = n; }
+    if (load_linear(m, prefix, "mlp.0", 1, &te->l1, err, errlen)) return -1;
+    if (load_linear(m, prefix, "mlp.2", 1, &te->l2, err, errlen)) return -1;
+    snprintf(key, sizeof key, "%smlp.3.alpha", prefix);
+    if (get_t(m, key, 0, &te->alpha, &sh, err, errlen)) return -1;
+    return 0;
+}
+
+static int model_build(po_model* m, char* err, int32_t errlen) {
+    char p[512]; const int64_t* sh;
+    /* ---- flow_lm.go:51-119 ---- */
+    if (get_t(m, "flow_lm.conditioner.embed.weight", 2, &m->embed, &sh, err, errlen)) return -1; /* conditioner.go:17 */
+    m->n_bins = sh[0]; m->d_model = sh[1];
+    int64_t heads = 16; /* DefaultFlowLMConfig flow_lm.go:20-27 */
+    m->n_layers = 0;
+    for (int i = 0; i < PO_MAX_LAYERS; i++) { /* flow_transformer.go:485-497 */
+        snprintf(p, sizeof p, "flow_lm.transformer.layers.%d.norm1.weight", i);
+        if (!has_tensor(m, p)) break;
+        flow_layer_t* L = &m->layers[i];
+        snprintf(p, sizeof p, "flow_lm.transformer.layers.%d.", i);
+        if (load_lnorm(m, p, "norm1", 1e-5f, &L->norm1, err, errlen)) return -1;
+        if (load_lnorm(m, p, "norm2", 1e-5f, &L->norm2, err, errlen)) return -1;
+        if (load_linear(m, p, "self_attn.in_proj", 0, &L->in_proj, err, errlen)) return -1;
+        if (load_linear(m, p, "self_attn.out_proj", 0, &L->out_proj, err, errlen)) return -1;
+        if (load_linear(m, p, "linear1", 0, &L->linear1, err, errlen)) return -1;
+        if (load_linear(m, p, "linear2", 0, &L->linear2, err, errlen)) return -1;
+        int64_t dm = L->out_proj.out;
+        if (dm % heads) FAIL("native: d_model %lld not divisible by num_heads %lld", (long long)dm, (long long)heads);
+        L->heads = heads; L->head_dim = dm / heads;
+        m->n_layers++;
+    }
+    if (m->n_layers == 0) FAIL("native: no flow_lm transformer layers found");
+    m->head_dim = m->layers[0].head_dim;
+    build_rope(PO_ROPE_SEQ, m->head_dim, 10000.0, &m->rope_cos, &m->rope_sin);
+    m->ldim = 32;
+    if (get_t(m, "flow_lm.emb_std", 1, &m->emb_std, &sh, err, errlen)) return -1;
+    if (sh[0] != m->ldim) FAIL("native varbuilder: tensor \"flow_lm.emb_std\" shape does not match expected [32]");
+    if (get_t(m, "flow_lm.emb_mean", 1, &m->emb_mean, &sh, err, errlen)) return -1;
+    if (get_t(m, "flow_lm.bos_emb", 1, &m->bos_emb, &sh, err, errlen)) return -1;
+    if (load_linear(m, "flow_lm.", "input_linear", 1, &m->input_linear, err, errlen)) return -1;
+    if (load_lnorm(m, "flow_lm.", "out_norm", 1e-5f, &m->out_norm, err, errlen)) return -1;
+    if (load_linear(m, "flow_lm.", "out_eos", 1, &m->out_eos, err, errlen)) return -1;
+    /* ---- flow_net.go:250-305 ---- */
+    if (load_tembed(m, "flow_lm.flow_net.time_embed.0.", &m->tembed[0], err, errlen)) return -1;
+    if (load_tembed(m, "flow_lm.flow_net.time_embed.1.", &m->tembed[1], err, errlen)) return -1;
+    if (load_linear(m, "flow_lm.flow_net.", "cond_embed", 1, &m->cond_embed, err, errlen)) return -1;
+    if (load_linear(m, "flow_lm.flow_net.", "input_proj", 1, &m->input_proj, err, errlen)) return -1;
+    m->n_res = 0;
+    for (int i = 0; i < PO_MAX_LAYERS; i++) {
+        snprintf(p, sizeof p, "flow_lm.flow_net.res_blocks.%d.in_ln.weight", i);
+        if (!has_tensor(m, p)) break;
+        snprintf(p, sizeof p, "flow_lm.flow_net.res_blocks.%d.", i);
+        resblock_t* rb = &m->res[i];
+        if (load_lnorm(m, p, "in_ln", 1e-6f, &rb->in_ln, err, errlen)) return -1;
+        if (load_linear(m, p, "mlp.0", 1, &rb->mlp0, err, errlen)) return -1;
+        if (load_linear(m, p, "mlp.2", 1, &rb->mlp2, err, errlen)) return -1;
+        if (load_linear(m, p, "adaLN_modulation.1", 1, &rb->ada, err, errlen)) return -1;
+        m->n_res++;
+    }
+    if (m->n_res == 0) FAIL("native: no flow_net res blocks found");
+    m->flow_dim = m->input_proj.out;
+    if (load_linear(m, "flow_lm.flow_net.final_layer.", "linear", 1, &m->final_linear, err, errlen)) return -1;
+    if (load_linear(m, "flow_lm.flow_net.final_layer.", "adaLN_modulation.1", 1, &m->final_ada, err, errlen)) return -1;
+    /* ---- mimi.go:546-637 ---- */
+    if (load_conv(m, "mimi.quantizer.output_proj", 0, &m->quant, err, errlen)) return -1;
+    if (load_convtr(m, "mimi.upsample.convtr.convtr", 16, 512, 0, &m->upsample, err, errlen)) return -1;
+    int64_t mheads = 8, mctx = 250; /* DefaultMimiConfig mimi.go:25-34 */
+    m->n_mimi_layers = 0;
+    for (int i = 0; i < PO_MAX_LAYERS; i++) {
+        snprintf(p, sizeof p, "mimi.decoder_transformer.transformer.layers.%d.norm1.weight", i);
+        if (!has_tensor(m, p)) break;
+        snprintf(p, sizeof p, "mimi.decoder_transformer.transformer.layers.%d.", i);
+        mimi_layer_t* L = &m->mimi_layers[i];
+        if (load_lnorm(m, p, "norm1", 1e-5f, &L->norm1, err, errlen)) return -1;
+        if (load_lnorm(m, p, "norm2", 1e-5f, &L->norm2, err, errlen)) return -1;
+        if (load_linear(m, p, "self_attn.in_proj", 0, &L->in_proj, err, errlen)) return -1;
+        if (load_linear(m, p, "self_attn.out_proj", 0, &L->out_proj, err, errlen)) return -1;
+        if (load_linear(m, p, "linear1", 0, &L->linear1, err, errlen)) return -1;
+        if (load_linear(m, p, "linear2", 0, &L->linear2, err, errlen)) return -1;
+        char key[600]; int ti;
+        snprintf(key, sizeof key, "%slayer_scale_1.scale", p); ti = find_tensor(m, key); L->ls1 = ti >= 0 ? m->data[ti] : NULL;
+        snprintf(key, sizeof key, "%slayer_scale_2.scale", p); ti = find_tensor(m, key); L->ls2 = ti >= 0 ? m->data[ti] : NULL;
+        int64_t dm = L->out_proj.out;
+        if (dm % mheads) FAIL("native: mimi d_model %lld not divisible by heads %lld", (long long)dm, (long long)mheads);
+        L->heads = mheads; L->head_dim = dm / mheads; L->context = mctx;
+        m->n_mimi_layers++;
+    }
+    if (m->n_mimi_layers == 0) FAIL("native: no mimi decoder transformer layers found");
+    m->mimi_dim = m->mimi_layers[0].out_proj.out;
+    build_rope(PO_ROPE_SEQ, m->mimi_layers[0].head_dim, 10000.0, &m->mimi_cos, &m->mimi_sin);
+    if (load_conv(m, "mimi.decoder.model.0.conv", 1, &m->init_conv, err, errlen)) return -1;
+    static const int up_idx[3] = { 2, 5, 8 }, rb_idx[3] = { 3, 6, 9 }; static const int64_t up_stride[3] = { 6, 5, 4 };
+    for (int i = 0; i < 3; i++) {
+        snprintf(p, sizeof p, "mimi.decoder.model.%d.convtr", up_idx[i]);
+        if (load_convtr(m, p, up_stride[i], 1, 1, &m->up[i], err, errlen)) return -1;
+        snprintf(p, sizeof p, "mimi.decoder.model.%d.block.1.conv", rb_idx[i]);
+        if (load_conv(m, p, 1, &m->rb[i].conv1, err, errlen)) return -1;
+        snprintf(p, sizeof p, "mimi.decoder.model.%d.block.3.conv", rb_idx[i]);
+        if (load_conv(m, p, 1, &m->rb[i].conv2, err, errlen)) return -1;
+    }
+    if (load_conv(m, "mimi.decoder.model.11.conv", 1, &m->final_conv, err, errlen)) return -1;
+    /* ---- model.go:176-250 newLatentToMimiProjector ---- */
+    m->proj_w = NULL; m->proj_b = NULL;
+    if (m->quant.k == 1 && m->quant.in_ch == m->ldim && m->quant.out_ch > 0) {
+        int64_t oc_n = m->quant.out_ch, ic_n = m->quant.in_ch;
+        m->proj_w = (float*)xmalloc(sizeof(float) * (size_t)(oc_n * ic_n));
+        m->proj_b = (float*)xmalloc(sizeof(float) * (size_t)oc_n);
+        for (int64_t oc = 0; oc < oc_n; oc++) {
+            float bv = m->quant.b ? m->quant.b[oc] : 0.0f;
+            for (int64_t ic = 0; ic < ic_n; ic++) {
+                float w = m->quant.w[oc * ic_n + ic];
+                m->proj_w[oc * ic_n + ic] = w * m->emb_std[ic];
+                float t = w * m->emb_mean[ic];
+                bv = bv + t;
+            }
+            m->proj_b[oc] = bv;
+        }
+        m->proj_in = ic_n; m->proj_out = oc_n;
+    }
+    return 0;
+}
+
+po_model* po_model_create(const po_tensor* tensors, int32_t n, char* err, int32_t errlen) {
+    po_model* m = (po_model*)calloc(1, sizeof(po_model));
+    m->n = n;
+    m->names = (char**)xmalloc(sizeof(char*) * (size_t)n);
+    m->data = (float**)xmalloc(sizeof(float*) * (size_t)n);
+    m->shapes = (int64_t**)xmalloc(sizeof(int64_t*) * (size_t)n);
+    m->ranks = (int32_t*)xmalloc(sizeof(int32_t) * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        m->names[i] = strdup(tensors[i].name);
+        m->ranks[i] = tensors[i].rank;
+        m->shapes[i] = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)(tensors[i].rank + 1));
+        int64_t cnt = 1;
+        for (int r = 0; r < tensors[i].rank; r++) { m->shapes[i][r] = tensors[i].shape[r]; cnt *= tensors[i].shape[r]; }
+        m->data[i] = (float*)xmalloc(sizeof(float) * (size_t)(cnt > 0 ? cnt : 1));
+        memcpy(m->data[i], tensors[i].data, sizeof(float) * (size_t)cnt); /* tensor.New copies (tensor.go:26-27) */
+    }
+    if (model_build(m, err, errlen)) { po_model_free(m); return NULL; }
+    return m;
+}
+
+void po_model_free(po_model* m) {
+    if (!m) return;
+    for (int i = 0; i < m->n; i++) { free(m->names[i]); free(m->data[i]); free(m->shapes[i]); }
+    free(m->names); free(m->data); free(m->shapes); free(m->ranks);
+    free(m->rope_cos); free(m->rope_sin); free(m->mimi_cos); free(m->mimi_sin);
+    free(m->proj_w); free(m->proj_b);
+    free(m);
+}
+
+int po_model_dims(const po_model* m, int64_t* o) {
+    o[0] = m->d_model; o[1] = m->layers[0].heads; o[2] = m->n_layers; o[3] = m->ldim;
+    o[4] = m->flow_dim; o[5] = m->n_res; o[6] = m->mimi_dim; o[7] = m->n_bins;
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* state (flow_transformer.go:26-108, 437-449, 642-715) */
+
+typedef struct { float *k, *v; int64_t cap, offset; } layer_state_t; /* [H, cap, Dh] (B == 1) */
+struct po_state { int64_t n_layers, heads, head_dim; layer_state_t* l; };
+
+po_state* po_state_new(const po_model* m) {
+    po_state* s = (po_state*)calloc(1, sizeof(po_state));
+    s->n_layers = m->n_layers; s->heads = m->layers[0].heads; s->head_dim = m->head_dim;
+    s->l = (layer_state_t*)calloc((size_t)m->n_layers, sizeof(layer_state_t));
+    return s;
+}
+void po_state_free(po_state* s) {
+    if (!s) return;
+    for (int64_t i = 0; i < s->n_layers; i++) { free(s->l[i].k); free(s->l[i].v); }
+    free(s->l); free(s);
+}
+int64_t po_state_offset(const po_state* s, int layer) { return s->l[layer].offset; }
+
+int po_state_read_kv(const po_state* s, int layer, float* k, float* v) {
+    const layer_state_t* L = &s->l[layer]; int64_t hd = s->head_dim;
+    for (int64_t h = 0; h < s->heads; h++)
+        for (int64_t t = 0; t < L->offset; t++) {
+            memcpy(k + (h * L->offset + t) * hd, L->k + (h * L->cap + t) * hd, sizeof(float) * (size_t)hd);
+            memcpy(v + (h * L->offset + t) * hd, L->v + (h * L->cap + t) * hd, sizeof(float) * (size_t)hd);
+        }
+    return 0;
+}
+
+static void grow_cache(layer_state_t* L, int64_t heads, int64_t hd, int64_t needed) { /* :69-108, 642-683 */
+    if (needed <= L->cap) return;
+    int64_t cur = L->cap < 1 ? 1 : L->cap, next = cur;
+    while (next < needed) next *= 2;
+    float* nk = fzeros(heads * next * hd); float* nv = fzeros(heads * next * hd);
+    for (int64_t h = 0; h < heads; h++)
+        for (int64_t t = 0; t < L->cap; t++) {
+            memcpy(nk + (h * next + t) * hd, L->k + (h * L->cap + t) * hd, sizeof(float) * (size_t)hd);
+            memcpy(nv + (h * next + t) * hd, L->v + (h * L->cap + t) * hd, sizeof(float) * (size_t)hd);
+        }
+    free(L->k); free(L->v); L->k = nk; L->v = nv; L->cap = next;
+}
+
+/* k,v: [H, T, Dh] */
+static void append_kv(layer_state_t* L, int64_t heads, int64_t hd, const float* k, const float* v, int64_t t) { /* :32-67 */
+    if (!L->k) {
+        L->k = (float*)xmalloc(sizeof(float) * (size_t)(heads * t * hd));
+        L->v = (float*)xmalloc(sizeof(float) * (size_t)(heads * t * hd));
+        memcpy(L->k, k, sizeof(float) * (size_t)(heads * t * hd));
+        memcpy(L->v, v, sizeof(float) * (size_t)(heads * t * hd));
+        L->cap = t; L->offset += t;
+        return;
+    }
+    grow_cache(L, heads, hd, L->offset + t);
+    for (int64_t h = 0; h < heads; h++)
+        for (int64_t s = 0; s < t; s++) {
+            memcpy(L->k + (h * L->cap + L->offset + s) * hd, k + (h * t + s) * hd, sizeof(float) * (size_t)hd);
+            memcpy(L->v + (h * L->cap + L->offset + s) * hd, v + (h * t + s) * hd, sizeof(float) * (size_t)hd);
+        }
+    L->offset += t;
+}
+
+po_state* po_state_from_voice(const po_model* m, const float* const* caches, const int64_t* steps,
+                              const int64_t* offsets, char* err, int32_t errlen) { /* :451-552 */
+    po_state* s = po_state_new(m);
+    for (int64_t i = 0; i < m->n_layers; i++) {
+        int64_t T = steps[i], H = s->heads, D = s->head_dim;
+        if (offsets[i] < 0) { if (err) snprintf(err, (size_t)errlen, "native: voice model state module has negative offset %lld", (long long)offsets[i]); po_state_free(s); return NULL; }
+        if (offsets[i] > T) { if (err) snprintf(err, (size_t)errlen, "native: voice model state module offset %lld exceeds cache length %lld", (long long)offsets[i], (long long)T); po_state_free(s); return NULL; }
+        s->l[i].k = fzeros(H * T * D); s->l[i].v = fzeros(H * T * D);
+        po_split_voice_kv(caches[i], 1, T, H, D, s->l[i].k, s->l[i].v);
+        s->l[i].cap = T; s->l[i].offset = offsets[i];
+    }
+    return s;
+}
+
+/* ------------------------------------------------------------------------- */
+/* flow transformer layer (flow_transformer.go:194-256, 295-389) */
+
+static void lin_fwd(const lin_t* l, const float* x, int64_t batch, float* y) { po_linear(x, l->w, l->b, batch, l->in, l->out, y); }
+static void ln_fwd(const lnorm_t* n, const float* x, int64_t outer, float* y) { po_layernorm(x, n->w, n->b, n->eps, outer, n->d, y); }
+
+/* qkv [T, 3D] -> q,k,v [H, T, Dh] (split + reshape + transpose(1,2)) tensor_util.go:144-173, flow_transformer.go:210-243 */
+static void split_heads(const float* qkv, int64_t t, int64_t heads, int64_t hd, float* q, float* k, float* v) {
+    int64_t d = heads * hd;
+    for (int64_t ti = 0; ti < t; ti++)
+        for (int64_t h = 0; h < heads; h++) {
+            memcpy(q + (h * t + ti) * hd, qkv + ti * 3 * d + 0 * d + h * hd, sizeof(float) * (size_t)hd);
+            memcpy(k + (h * t + ti) * hd, qkv + ti * 3 * d + 1 * d + h * hd, sizeof(float) * (size_t)hd);
+            memcpy(v + (h * t + ti) * hd, qkv + ti * 3 * d + 2 * d + h * hd, sizeof(float) * (size_t)hd);
+        }
+}
+static void merge_heads(const float* a, int64_t t, int64_t heads, int64_t hd, float* out) { /* transpose(1,2)+reshape */
+    for (int64_t h = 0; h < heads; h++)
+        for (int64_t ti = 0; ti < t; ti++)
+            memcpy(out + ti * heads * hd + h * hd, a + (h * t + ti) * hd, sizeof(float) * (size_t)hd);
+}
+
+/* x [T, D] in/out; forwardWithState :326-389 */
+static int flow_layer_with_state(const po_model* m, const flow_layer_t* L, layer_state_t* st, float* x, int64_t t) {
+    int64_t d = m->d_model, H = L->heads, hd = L->head_dim;
+    float* n1 = fzeros(t * d); float* qkv = fzeros(t * 3 * d);
+    float* q = fzeros(t * d); float* k = fzeros(t * d); float* v = fzeros(t * d);
+    ln_fwd(&L->norm1, x, t, n1);
+    int64_t pos = st->offset;
+    lin_fwd(&L->in_proj, n1, t, qkv);
+    split_heads(qkv, t, H, hd, q, k, v);
+    if (pos + t > PO_ROPE_SEQ) { free(n1); free(qkv); free(q); free(k); free(v); return -3; }
+    po_rope(q, m->rope_cos, m->rope_sin, H, t, hd, pos);
+    po_rope(k, m->rope_cos, m->rope_sin, H, t, hd, pos);
+    append_kv(st, H, hd, k, v, t);
+    int64_t cap = st->cap, klen = st->offset;
+    int64_t* posq = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)t);
+    int64_t* posk = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)cap);
+    for (int64_t i = 0; i < t; i++) posq[i] = pos + i;                      /* positionsRange :391-402 */
+    for (int64_t i = 0; i < cap; i++) posk[i] = i < klen ? i : -1;          /* cachePositions :404-420 */
+    float* a = fzeros(t * d);
+    int rc = po_attention_positions(q, st->k, st->v, 1, H, t, cap, hd, hd, posq, posk, -1, a);
+    float* am = fzeros(t * d); merge_heads(a, t, H, hd, am);
+    float* proj = fzeros(t * d); lin_fwd(&L->out_proj, am, t, proj);
+    for (int64_t i = 0; i < t * d; i++) x[i] += proj[i];                    /* addSameShape */
+    float* n2 = fzeros(t * d); ln_fwd(&L->norm2, x, t, n2);
+    int64_t f = L->linear1.out;
+    float* ff = fzeros(t * f); lin_fwd(&L->linear1, n2, t, ff);
+    po_gelu_erf(ff, t * f);
+    float* ff2 = fzeros(t * d); lin_fwd(&L->linear2, ff, t, ff2);
+    for (int64_t i = 0; i < t * d; i++) x[i] += ff2[i];
+    free(n1); free(qkv); free(q); free(k); free(v); free(posq); free(posk); free(a); free(am); free(proj);
+    free(n2); free(ff); free(ff2);
+    return rc;
+}
+
+/* stateless layer.forward :158-192 (causal, offset 0) */
+static int flow_layer_full(const po_model* m, const flow_layer_t* L, float* x, int64_t t) {
+    int64_t d = m->d_model, H = L->heads, hd = L->head_dim;
+    float* n1 = fzeros(t * d); float* qkv = fzeros(t * 3 * d);
+    float* q = fzeros(t * d); float* k = fzeros(t * d); float* v = fzeros(t * d);
+    ln_fwd(&L->norm1, x, t, n1);
+    lin_fwd(&L->in_proj, n1, t, qkv);
+    split_heads(qkv, t, H, hd, q, k, v);
+    po_rope(q, m->rope_cos, m->rope_sin, H, t, hd, 0);
+    po_rope(k, m->rope_cos, m->rope_sin, H, t, hd, 0);
+    float* a = fzeros(t * d);
+    int rc = po_attention(q, k, v, 1, H, t, t, hd, hd, 1, 0, a);
+    float* am = fzeros(t * d); merge_heads(a, t, H, hd, am);
+    float* proj = fzeros(t * d); lin_fwd(&L->out_proj, am, t, proj);
+    for (int64_t i = 0; i < t * d; i++) x[i] += proj[i];
+    float* n2 = fzeros(t * d); ln_fwd(&L->norm2, x, t, n2);
+    int64_t f = L->linear1.out;
+    float* ff = fzeros(t * f); lin_fwd(&L->linear1, n2, t, ff);
+    po_gelu_erf(ff, t * f);
+    float* ff2 = fzeros(t * d); lin_fwd(&L->linear2, ff, t, ff2);
+    for (int64_t i = 0; i < t * d; i++) x[i] += ff2[i];
+    free(n1); free(qkv); free(q); free(k); free(v); free(a); free(am); free(proj); free(n2); free(ff); free(ff2);
+    return rc;
+}
+
+int po_text_embeddings(const po_model* m, const int64_t* ids, int64_t n, float* out, char* err, int32_t errlen) {
+    for (int64_t i = 0; i < n; i++) { /* conditioner.go:40-45 */
+        if (ids[i] < 0 || ids[i] >= m->n_bins) FAIL("native: token id %lld (%lld) out of range [0,%lld)", (long long)i, (long long)ids[i], (long long)m->n_bins);
+    }
+    for (int64_t i = 0; i < n; i++) memcpy(out + i * m->d_model, m->embed + ids[i] * m->d_model, sizeof(float) * (size_t)m->d_model);
+    return 0;
+}
+
+int po_prompt(const po_model* m, po_state* s, const float* emb, int64_t t) { /* flow_lm.go:155-187, flow_transformer.go:749-771 */
+    if (t == 0) return 0;
+    float* x = (float*)xmalloc(sizeof(float) * (size_t)(t * m->d_model));
+    memcpy(x, emb, sizeof(float) * (size_t)(t * m->d_model));
+    int rc = 0;
+    for (int64_t i = 0; i < m->n_layers && rc == 0; i++) rc = flow_layer_with_state(m, &m->layers[i], &s->l[i], x, t);
+    free(x);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* flow net (flow_net.go) */
+
+static void tembed_fwd(const tembed_t* te, float tval, float* out /*[l2.out]*/) { /* flow_net.go:42-83 (B == 1) */
+    int64_t nf = te->nfreq;
+    float* emb = fzeros(2 * nf);
+    for (int64_t i = 0; i < nf; i++) {
+        float arg = tval * te->freqs[i];                 /* BroadcastMul, f32 */
+        emb[i]      = (float)cos((double)arg);           /* mimi.go:796-797 cosf/sinf in f64 */
+        emb[nf + i] = (float)sin((double)arg);
+    }
+    float* h = fzeros(te->l1.out);
+    lin_fwd(&te->l1, emb, 1, h);
+    po_silu(h, te->l1.out);
+    lin_fwd(&te->l2, h, 1, out);
+    po_rmsnorm_alpha(out, te->alpha, 1e-5f, 1, te->l2.out);
+    free(emb); free(h);
+}
+
+static void modulate(float* x, const float* shift, const float* scale, int64_t n) { /* tensor_util.go:175-193 */
+    for (int64_t i = 0; i < n; i++) { float ops = scale[i] + 1.0f; float mul = x[i] * ops; x[i] = mul + shift[i]; }
+}
+
+int po_flow_direction(const po_model* m, const float* c, float sv, float tv, const float* x, float* out) { /* :314-356 */
+    int64_t C = m->flow_dim;
+    float* xp = fzeros(C); lin_fwd(&m->input_proj, x, 1, xp);
+    float* t0 = fzeros(C); float* t1 = fzeros(C);
+    tembed_fwd(&m->tembed[0], sv, t0);
+    tembed_fwd(&m->tembed[1], tv, t1);
+    float* y = fzeros(C);
+    for (int64_t i = 0; i < C; i++) { float tc = t0[i] + t1[i]; y[i] = tc * 0.5f; }
+    float* cp = fzeros(C); lin_fwd(&m->cond_embed, c, 1, cp);
+    for (int64_t i = 0; i < C; i++) y[i] = y[i] + cp[i];
+    float* sy = fzeros(C); memcpy(sy, y, sizeof(float) * (size_t)C); po_silu(sy, C);
+    float* ada = fzeros(3 * C); float* h = fzeros(C); float* h2 = fzeros(C);
+    for (int64_t r = 0; r < m->n_res; r++) { /* flowResBlock.Forward :116-172 */
+        const resblock_t* rb = &m->res[r];
+        lin_fwd(&rb->ada, sy, 1, ada);
+        ln_fwd(&rb->in_ln, xp, 1, h);
+        modulate(h, ada /*shift*/, ada + C /*scale*/, C);
+        lin_fwd(&rb->mlp0, h, 1, h2);
+        po_silu(h2, C);
+        lin_fwd(&rb->mlp2, h2, 1, h);
+        for (int64_t i = 0; i < C; i++) { float g = h[i] * ada[2 * C + i]; xp[i] = xp[i] + g; }
+    }
+    /* flowFinalLayer.Forward :205-239 */
+    lin_fwd(&m->final_ada, sy, 1, ada);
+    po_layernorm(xp, NULL, NULL, 1e-6f, 1, C, h); /* ones/zeros affine == identity */
+    /* tensor.LayerNorm with weight=ones, bias=zeros multiplies by 1 and adds 0: exact identity */
+    modulate(h, ada, ada + C, C);
+    lin_fwd(&m->final_linear, h, 1, out);
+    free(xp); free(t0); free(t1); free(y); free(cp); free(sy); free(ada); free(h); free(h2);
+    return 0;
+}
+
+static void lsd_decode(const po_model* m, const float* cond, const float* x0, int steps, float* out) { /* flow_lm.go:311-353 */
+    int64_t D = m->ldim;
+    memcpy(out, x0, sizeof(float) * (size_t)D);
+    float inv = 1.0f / (float)steps;
+    float* flow = fzeros(D);
+    for (int i = 0; i < steps; i++) {
+        float sv = (float)i / (float)steps, tv = (float)(i + 1) / (float)steps;
+        po_flow_direction(m, cond, sv, tv, out, flow);
+        for (int64_t j = 0; j < D; j++) { float p = flow[j] * inv; out[j] = out[j] + p; }
+    }
+    free(flow);
+}
+
+int po_step(const po_model* m, po_state* s, const float* frame_in, int lsd_steps, float eos_threshold,
+            const float* noise, float* frame_out, int* is_eos, float* eos_logit, float* last_hidden) { /* flow_lm.go:238-299 */
+    int64_t D = m->d_model, L = m->ldim;
+    if (lsd_steps <= 0) return -1;
+    float* seq = (float*)xmalloc(sizeof(float) * (size_t)L);
+    memcpy(seq, frame_in, sizeof(float) * (size_t)L);
+    po_replace_nan(seq, L, m->bos_emb, L);
+    float* x = fzeros(D);
+    lin_fwd(&m->input_linear, seq, 1, x);
+    int rc = 0;
+    for (int64_t i = 0; i < m->n_layers && rc == 0; i++) rc = flow_layer_with_state(m, &m->layers[i], &s->l[i], x, 1);
+    float* last = fzeros(D);
+    ln_fwd(&m->out_norm, x, 1, last);
+    float eos = 0; lin_fwd(&m->out_eos, last, 1, &eos);
+    if (is_eos) *is_eos = eos > eos_threshold;
+    if (eos_logit) *eos_logit = eos;
+    if (last_hidden) memcpy(last_hidden, last, sizeof(float) * (size_t)D);
+    float* x0 = fzeros(L);
+    if (noise) memcpy(x0, noise, sizeof(float) * (size_t)L);
+    lsd_decode(m, last, x0, lsd_steps, frame_out);
+    free(seq); free(x); free(last); free(x0);
+    return rc;
+}
+
+int po_flow_main(const po_model* m, const float* seq, int64_t s, const float* text, int64_t t,
+                 float* last_hidden, float* eos_logit) { /* flow_lm.go:192-233 */
+    int64_t D = m->d_model, L = m->ldim, n = t + s;
+    float* sq = (float*)xmalloc(sizeof(float) * (size_t)(s * L));
+    memcpy(sq, seq, sizeof(float) * (size_t)(s * L));
+    po_replace_nan(sq, s * L, m->bos_emb, L);
+    float* x = fzeros(n * D);
+    memcpy(x, text, sizeof(float) * (size_t)(t * D));
+    lin_fwd(&m->input_linear, sq, s, x + t * D);
+    int rc = 0;
+    for (int64_t i = 0; i < m->n_layers && rc == 0; i++) rc = flow_layer_full(m, &m->layers[i], x, n);
+    float* xn = fzeros(n * D);
+    ln_fwd(&m->out_norm, x, n, xn);
+    memcpy(last_hidden, xn + (n - 1) * D, sizeof(float) * (size_t)D);
+    lin_fwd(&m->out_eos, last_hidden, 1, eos_logit);
+    free(sq); free(x); free(xn);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* latent -> mimi, mimi decode */
+
+int po_latent_to_mimi(const po_model* m, const float* latent, int64_t t, float* out) { /* model.go:252-319 */
+    if (m->proj_w) {
+        for (int64_t oc = 0; oc < m->proj_out; oc++) {
+            const float* wrow = m->proj_w + oc * m->proj_in; float bv = m->proj_b[oc];
+            for (int64_t ti = 0; ti < t; ti++) out[oc * t + ti] = dot_f32(latent + ti * m->proj_in, wrow, m->proj_in) + bv;
+        }
+        return 0;
+    }
+    /* fallback model.go:159-166 */
+    float* den = fzeros(m->ldim * t);
+    po_denorm_latent_to_bct(latent, m->emb_std, m->emb_mean, 1, t, m->ldim, den);
+    int rc = po_conv1d(den, m->quant.w, m->quant.b, 1, m->quant.in_ch, t, m->quant.out_ch, m->quant.k, 1, 0, 0, 1, 1, out);
+    free(den);
+    return rc;
+}
+
+/* conv1dLayer.forwardStreamingOnce mimi.go:69-76 (stride 1, dilation 1, groups 1) */
+static float* conv_stream(const conv_t* c, const float* x, int64_t len, int64_t* out_len) {
+    int64_t eff = (c->k - 1) * 1 + 1, lpad = eff - 1; if (lpad < 0) lpad = 0;
+    *out_len = po_conv1d_outlen(len, c->k, 1, lpad, 0, 1);
+    float* out = fzeros(c->out_ch * *out_len);
+    po_conv1d(x, c->w, c->b, 1, c->in_ch, len, c->out_ch, c->k, 1, lpad, 0, 1, 1, out);
+    return out;
+}
+/* convTr1dLayer.forwardStreamingOnce mimi.go:116-125 */
+static float* convtr_stream(const convtr_t* c, const float* x, int64_t len, int64_t* out_len) {
+    int64_t pt = c->k - c->stride;
+    *out_len = po_convtr1d_outlen(len, c->k, c->stride, 0, 0, 1, pt);
+    float* out = fzeros(c->opg * c->groups * *out_len);
+    po_convtr1d(x, c->w, c->b, 1, c->in_ch, len, c->opg, c->k, c->stride, 0, 0, 1, c->groups, pt, out);
+    return out;
+}
+/* seanetResBlock.Forward mimi.go:146-164 ; x [C, len] updated in place */
+static void seanet_rb(const seanet_rb_t* rb, float* x, int64_t ch, int64_t len) {
+    float* h = (float*)xmalloc(sizeof(float) * (size_t)(ch * len));
+    memcpy(h, x, sizeof(float) * (size_t)(ch * len));
+    po_elu(h, ch * len);
+    int64_t l1, l2;
+    float* h1 = conv_stream(&rb->conv1, h, len, &l1);
+    po_elu(h1, rb->conv1.out_ch * l1);
+    float* h2 = conv_stream(&rb->conv2, h1, l1, &l2);
+    for (int64_t i = 0; i < ch * len; i++) x[i] += h2[i];
+    free(h); free(h1); free(h2);
+}
+
+/* mimiTransformerLayer.forwardWithScratch mimi.go:245-441; x [T, C] in place */
+static int mimi_layer(const po_model* m, const mimi_layer_t* L, float* x, int64_t t) {
+    int64_t d = m->mimi_dim, H = L->heads, hd = L->head_dim;
+    float* n1 = fzeros(t * d); ln_fwd(&L->norm1, x, t, n1);
+    float* qkv = fzeros(t * 3 * d); lin_fwd(&L->in_proj, n1, t, qkv);
+    float* q = fzeros(t * d); float* k = fzeros(t * d); float* v = fzeros(t * d);
+    split_heads(qkv, t, H, hd, q, k, v);
+    if (t > PO_ROPE_SEQ) return -3;
+    po_rope(q, m->mimi_cos, m->mimi_sin, H, t, hd, 0);
+    po_rope(k, m->mimi_cos, m->mimi_sin, H, t, hd, 0);
+    int64_t* pos = (int64_t*)xmalloc(sizeof(int64_t) * (size_t)t);
+    for (int64_t i = 0; i < t; i++) pos[i] = i;
+    float* a = fzeros(t * d);
+    int rc = po_attention_positions(q, k, v, 1, H, t, t, hd, hd, pos, pos, L->context, a);
+    float* am = fzeros(t * d); merge_heads(a, t, H, hd, am);
+    float* attn = fzeros(t * d); lin_fwd(&L->out_proj, am, t, attn);
+    if (L->ls1) for (int64_t i = 0; i < t * d; i++) attn[i] *= L->ls1[i % d];       /* mulLastDimInPlace */
+    for (int64_t i = 0; i < t * d; i++) x[i] += attn[i];
+    float* n2 = fzeros(t * d); ln_fwd(&L->norm2, x, t, n2);
+    int64_t f = L->linear1.out;
+    float* ff = fzeros(t * f); lin_fwd(&L->linear1, n2, t, ff);
+    po_gelu_erf(ff, t * f);
+    float* ff2 = fzeros(t * d); lin_fwd(&L->linear2, ff, t, ff2);
+    if (L->ls2) for (int64_t i = 0; i < t * d; i++) ff2[i] *= L->ls2[i % d];
+    for (int64_t i = 0; i < t * d; i++) x[i] += ff2[i];
+    free(n1); free(qkv); free(q); free(k); free(v); free(pos); free(a); free(am); free(attn); free(n2); free(ff); free(ff2);
+    return rc;
+}
+
+static void transpose2d(const float* in, int64_t r, int64_t c, float* out) { /* [r,c] -> [c,r] */
+    for (int64_t i = 0; i < r; i++) for (int64_t j = 0; j < c; j++) out[j * r + i] = in[i * c + j];
+}
+
+int64_t po_mimi_out_len(const po_model* m, int64_t t) { /* length bookkeeping of mimi.go:719-789 */
+    int64_t len = po_convtr1d_outlen(t, m->upsample.k, m->upsample.stride, 0, 0, 1, m->upsample.k - m->upsample.stride);
+    len = po_conv1d_outlen(len, m->init_conv.k, 1, m->init_conv.k - 1, 0, 1);
+    for (int i = 0; i < 3; i++) len = po_convtr1d_outlen(len, m->up[i].k, m->up[i].stride, 0, 0, 1, m->up[i].k - m->up[i].stride);
+    len = po_conv1d_outlen(len, m->final_conv.k, 1, m->final_conv.k - 1, 0, 1);
+    return len * m->final_conv.out_ch;
+}
+
+int po_mimi_decode(const po_model* m, const float* xin, int64_t t, float* pcm) { /* mimi.go:719-789 */
+    int64_t len; int rc = 0;
+    float* x = convtr_stream(&m->upsample, xin, t, &len);                     /* upsample */
+    int64_t C = m->mimi_dim;
+    float* xt = (float*)xmalloc(sizeof(float) * (size_t)(C * len));
+    transpose2d(x, C, len, xt);                                               /* [C,T] -> [T,C] */
+    for (int64_t i = 0; i < m->n_mimi_layers && rc == 0; i++) rc = mimi_layer(m, &m->mimi_layers[i], xt, len);
+    transpose2d(xt, len, C, x);
+    free(xt);
+    int64_t l2;
+    float* y = conv_stream(&m->init_conv, x, len, &l2); free(x); x = y; len = l2;   /* initConv */
+    int64_t ch = m->init_conv.out_ch;
+    po_elu(x, ch * len);
+    for (int i = 0; i < 3; i++) {
+        y = convtr_stream(&m->up[i], x, len, &l2); free(x); x = y; len = l2; ch = m->up[i].opg;
+        seanet_rb(&m->rb[i], x, ch, len);
+        po_elu(x, ch * len);
+    }
+    y = conv_stream(&m->final_conv, x, len, &l2); free(x);
+    memcpy(pcm, y, sizeof(float) * (size_t)(m->final_conv.out_ch * l2));
+    free(y);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------- */
+/* GenerateAudio (runtime_native_safetensors.go:52-238) */
+
+int po_generate(const po_model* m, const po_request* rq, po_result* res, char* err, int32_t errlen) {
+    memset(res, 0, sizeof *res); res->eos_step = -1;
+    if (rq->n_tokens == 0) FAIL("generate: token slice must not be empty");
+    int max_steps = rq->max_steps;
+    if (max_steps <= 0) max_steps = (int)ceil(((double)rq->n_tokens / 3.0 + 2.0) * 12.5); /* text/prepare.go:38-48 */
+    int lsd = rq->lsd_steps <= 0 ? 1 : rq->lsd_steps;
+    int64_t D = m->d_model, L = m->ldim;
+    if (rq->voice_emb && rq->voice_caches) FAIL("generate: voice embedding and voice model state are mutually exclusive");
+    int64_t tp = rq->n_tokens + (rq->voice_emb ? rq->voice_t : 0);
+    float* emb = fzeros(tp * D);
+    int64_t off = 0;
+    if (rq->voice_emb) { memcpy(emb, rq->voice_emb, sizeof(float) * (size_t)(rq->voice_t * D)); off = rq->voice_t; } /* :104-119 */
+    char e2[256];
+    if (po_text_embeddings(m, rq->tokens, rq->n_tokens, emb + off * D, e2, sizeof e2)) { free(emb); FAIL("generate: text embeddings: %s", e2); }
+    po_state* st;
+    if (rq->voice_caches) {
+        st = po_state_from_voice(m, rq->voice_caches, rq->voice_steps, rq->voice_offsets, e2, sizeof e2);
+        if (!st) { free(emb); FAIL("generate: load voice model state: %s", e2); }
+    } else st = po_state_new(m);
+    if (po_prompt(m, st, emb, tp)) { free(emb); po_state_free(st); FAIL("generate: prompt flow state: failed"); }
+    free(emb);
+    float* frames = fzeros((int64_t)max_steps * L);
+    float* cur = (float*)xmalloc(sizeof(float) * (size_t)L);
+    for (int64_t i = 0; i < L; i++) cur[i] = NAN;                             /* newBOSSequenceTensor :246-253 */
+    int n_frames = 0, countdown = 0, have_countdown = 0;
+    for (int step = 0; step < max_steps; step++) {                            /* :155-201 */
+        int is_eos = 0;
+        float* fo = frames + (int64_t)step * L;
+        int rc = po_step(m, st, cur, lsd, rq->eos_threshold, rq->noise ? rq->noise + (int64_t)step * L : NULL, fo, &is_eos, NULL, NULL);
+        if (rc) { free(frames); free(cur); po_state_free(st); FAIL("generate step %d: failed", step); }
+        n_frames++;
+        if (is_eos && !have_countdown) { have_countdown = 1; countdown = rq->frames_after_eos; res->eos_step = step; }
+        if (have_countdown) { if (countdown == 0) break; countdown--; }
+        memcpy(cur, fo, sizeof(float) * (size_t)L);
+    }
+    free(cur); po_state_free(st);
+    int64_t T = n_frames;
+    float* ml = fzeros(m->mimi_dim * T);
+    po_latent_to_mimi(m, frames, T, ml);
+    int64_t n_samples = po_mimi_out_len(m, T);
+    res->pcm = fzeros(n_samples);
+    if (po_mimi_decode(m, ml, T, res->pcm)) { free(ml); free(frames); free(res->pcm); res->pcm = NULL; FAIL("generate: mimi_decode: failed"); }
+    free(ml);
+    res->n_samples = n_samples;
+    res->latents = frames; res->n_frames = n_frames;
+    return 0;
+}
+
+void po_free_result(po_result* r) { if (!r) return; free(r->pcm); free(r->latents); r->pcm = NULL; r->latents = NULL; }
