@@ -1,0 +1,150 @@
+// kernels.h -- launchers of the hand-written gfx950 kernels (kernels.hip).
+// All pointers are device pointers; every launcher enqueues on `stream` and returns.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace ptts {
+
+// Rows of a 2-D operand may live in per-utterance segments (channels-last sequences with
+// zero "history" rows in front of each utterance): row r is at
+//   base + (r / rows_per_batch) * batch_stride + (r % rows_per_batch) * ld      (elements)
+// rows_per_batch == 0 means one flat segment (base + r * ld).
+struct RowMap {
+    int64_t ld = 0;
+    int64_t rows_per_batch = 0;
+    int64_t batch_stride = 0;
+};
+
+enum AOp : int { AOP_NONE = 0, AOP_ELU = 1 };
+enum Epi : int {
+    EPI_NONE = 0,        // C = acc + bias
+    EPI_GELU,            // C = gelu_erf(acc + bias)                     tensor_util.go:84-94
+    EPI_SILU,            // C = silu(addvec + (acc + bias))              tensor_util.go:73-82
+    EPI_ELU,             // C = elu(acc + bias)                          tensor_util.go:119-128
+    EPI_RESADD,          // C = R + (acc + bias)
+    EPI_SCALE_RESADD,    // C = R + scale[n] * (acc + bias)              mimi.go:275-285,351-358
+    EPI_GATE_RESADD,     // C = R + gate[m, n] * (acc + bias)            flow_net.go:166-171
+    EPI_AXPY,            // C = R + alpha * (acc + bias)                 flow_lm.go:346-349
+};
+
+struct GemmArgs {
+    // C[M, N] = epi( aop(A)[M, K] * W[N, K]^T )
+    const float* A = nullptr; RowMap amap;
+    const void*  W = nullptr; int w_bf16 = 0; int64_t ldw = 0;
+    const float* bias = nullptr;     // [N] or null
+    const float* addvec = nullptr;   // [N] or null (EPI_SILU only)
+    float*       C = nullptr; RowMap cmap;
+    const float* R = nullptr;        // residual, addressed like C
+    const float* scale = nullptr;    // [N]
+    const float* gate = nullptr; int64_t ldg = 0;
+    float alpha = 1.0f;
+    int M = 0, N = 0, K = 0;
+    int aop = AOP_NONE, epi = EPI_NONE;
+};
+void launch_gemm(const GemmArgs& a, hipStream_t stream);
+
+struct LnArgs {
+    const float* x = nullptr; RowMap xmap;
+    const float* w = nullptr; const float* b = nullptr;  // null -> no affine (flow_net.go:228)
+    float eps = 1e-5f;
+    // optional adaLN modulation y = y * (1 + scale[row]) + shift[row]   (tensor_util.go:175-193)
+    const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;
+    float* y = nullptr; int64_t ldy = 0;
+    int rows = 0, d = 0;
+};
+void launch_layernorm(const LnArgs& a, hipStream_t stream);
+// Bessel-variance "RMS" norm of the timestep embedder (tensor_util.go:273-326), in place
+void launch_rmsnorm_alpha(float* x, const float* alpha, float eps, int rows, int d, hipStream_t stream);
+
+// rows of `table` selected by ids (conditioner.go:47, shape_ops.go Gather)
+void launch_embed_gather(const float* table, const int64_t* ids, int n, int d, float* out, hipStream_t stream);
+// out[r, i] = isnan(in[r, i]) ? bos[i] : in[r, i]   (tensor_util.go:242-271); in_idx (optional) picks the source row
+void launch_replace_nan(const float* in, const float* bos, int rows, int d, float* out, hipStream_t stream);
+// elementwise helpers
+void launch_silu(float* x, int64_t n, hipStream_t stream);
+void launch_copy_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int d, hipStream_t stream);
+// out[r, c] = sin/cos timestep features: [cos(t*f) | sin(t*f)]  (flow_net.go:52-65)
+void launch_timestep_features(float t, const float* freqs, int nf, float* out, hipStream_t stream);
+// y[i] = 0.5 * (a[i] + b[i])   (flow_net.go:330-335)
+void launch_avg2(const float* a, const float* b, float* y, int n, hipStream_t stream);
+
+// interleaved-pair RoPE (rope.go:81-105) on rows of a [rows, ld] buffer: for each row r and head h the
+// vector at x + r*ld + col0 + h*hd is rotated with the table row pos[r]
+// position of row r: pos ? pos[r] : pos_base + (rows_per_seg ? r % rows_per_seg : r)
+void launch_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
+                      int rows, const float* cos_t, const float* sin_t, hipStream_t stream);
+
+// KV cache layout: [slot][head][capacity][hd]; append K/V rows taken from a qkv buffer [rows, 3*D]
+void launch_kv_append(const float* qkv, int64_t ld, int d_model, int heads, int hd, const int32_t* row_slot,
+                      const int32_t* row_pos, int rows, void* kcache, void* vcache, int kv_bf16, int64_t cap,
+                      hipStream_t stream);
+
+struct AttnArgs {
+    // one query per (row, head)
+    const float* q = nullptr; int64_t q_ld = 0; int q_col0 = 0;   // q vector at q + row*q_ld + q_col0 + h*hd
+    // keys/values: key j of (row, head) at kbase + seg(row)*k_seg_stride + h*k_head_stride + j*k_row_stride
+    const void* k = nullptr; const void* v = nullptr; int kv_bf16 = 0;
+    int64_t k_seg_stride = 0, k_head_stride = 0, k_row_stride = 0;
+    const int32_t* row_seg = nullptr;   // null: seg = row / rows_per_seg
+    int rows_per_seg = 0;
+    const int32_t* row_pos = nullptr;   // query position; null: pos = row % rows_per_seg
+    const int32_t* seg_len = nullptr;   // if set (AR step): pos = seg_len[seg], rope+append fused
+    int context = -1;                   // keys j with pos-context < j <= pos   (attention.go:473-484)
+    float* out = nullptr; int64_t out_ld = 0;  // out + row*out_ld + h*hd
+    int rows = 0, heads = 0, hd = 64;
+    int max_keys = 0;                   // upper bound on keys per query (sizes the LDS score buffer)
+    // fused RoPE + KV append for the AR step (flow_transformer.go:340-347): q,k,v read from a qkv row
+    int fused_step = 0; const float* qkv = nullptr; int64_t qkv_ld = 0; int d_model = 0;
+    const float* cos_t = nullptr; const float* sin_t = nullptr; int64_t cap = 0;
+    const int32_t* active = nullptr;    // per segment; inactive rows write zeros and append nothing
+};
+void launch_attention(const AttnArgs& a, hipStream_t stream);
+
+// latent [B, T, L] -> x[b, 1+t, :] = Wp * latent + bp  (model.go:252-319), row 0 of each utterance zeroed
+void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c,
+                      float* out, hipStream_t stream);
+// depthwise ConvTranspose1d k=2*stride, right-trimmed (convtranspose1d.go:154-202): in [B, 1+T, C] (row 0 = zeros) ->
+// out rows [B][pad + T*stride][C]; w0[r][c] multiplies x[t-1], w1[r][c] multiplies x[t]
+void launch_upsample_depthwise(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int c,
+                               int stride, float* out, int out_pad_rows, hipStream_t stream);
+// voice model-state ingestion (flow_transformer.go:568-631): raw [2,1,T,H,D] f32 -> first `offset` rows of a slot's K and V cache
+void launch_voice_scatter(const float* raw, int t, int heads, int hd, int offset, int slot, void* kcache, void* vcache,
+                          int kv_bf16, int64_t cap, hipStream_t stream);
+// final causal conv Cin -> 1, kernel k, ELU on the input (mimi.go:781-783): in [B][pad+T][C] channels-last
+void launch_conv_final(const float* in, int in_pad_rows, const float* w /*[k*C]*/, const float* bias, int b, int t, int c,
+                       int k, float* out /*[B][T]*/, hipStream_t stream);
+void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipStream_t stream);
+
+// AR-step bookkeeping (runtime_native_safetensors.go:176-192 per slot, on device)
+struct StepState {
+    int32_t* kv_len;        // [B] keys in the cache (== flowTransformerLayerState.offset)
+    int32_t* active;        // [B]
+    int32_t* step;          // [B] next frame index
+    int32_t* countdown;     // [B] -1 == nil
+    int32_t* n_frames;      // [B]
+    int32_t* eos_step;      // [B]
+    int32_t* max_steps;     // [B]
+    int32_t* frames_after_eos;  // [B]
+    float*   eos_threshold; // [B]
+    int32_t* n_active;      // [1]
+    int32_t* broke;         // [B] 1 when the loop left through the countdown `break` (no StepCallback for that step)
+};
+// prepares the step input: in32[b] = step==0 ? bos : latents[b][step-1] with NaN -> bos
+void launch_step_input(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, int ldim, int b,
+                       float* in32, hipStream_t stream);
+// x0[b] = noise ? noise[b][step] : 0
+void launch_step_noise(const StepState& s, const float* noise, int64_t noise_stride, int ldim, int b, float* x0,
+                       hipStream_t stream);
+// stores the decoded frame, applies EOS logic, advances kv_len/step
+void launch_step_finish(const StepState& s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,
+                        int64_t lat_stride, hipStream_t stream);
+void launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
+void launch_add_i32(int32_t* p, const int32_t* inc, int n, hipStream_t stream);
+
+// [B, C, T] <-> channels-last helpers for the op-level entry points
+void launch_bct_to_btc(const float* in, int b, int c, int t, float* out, int out_pad_rows, hipStream_t stream);
+void launch_btc_to_bct(const float* in, int in_pad_rows, int b, int c, int t, float* out, hipStream_t stream);
+
+}  // namespace ptts

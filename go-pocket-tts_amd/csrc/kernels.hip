@@ -1,0 +1,723 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the PocketTTS synthesis path.
+//
+// Each kernel names the reference computation it replaces.
+// Layout conventions: activations are row-major [rows, channels] ("channels-last" for the
+// Mimi decoder, so that a causal convolution window is one contiguous span and every
+// global access is a coalesced 16-byte-per-lane stream); weights are [out, in] row-major.
+#include "kernels.h"
+
+#include <cmath>
+
+namespace ptts {
+
+#define WAVE 64
+
+__device__ __forceinline__ int64_t row_off(const RowMap& m, int64_t r) {
+    return m.rows_per_batch ? (r / m.rows_per_batch) * m.batch_stride + (r % m.rows_per_batch) * m.ld : r * m.ld;
+}
+
+__device__ __forceinline__ float elu1(float v) { return v <= 0.0f ? expf(v) - 1.0f : v; }        // tensor_util.go:119-128
+__device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }                  // tensor_util.go:73-82
+__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // :84-94
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GEMM  C[M,N] = epi( aop(A)[M,K] * W[N,K]^T )       (K4, K8, K11, K13-K17: every Linear / Conv1d /
+// ConvTranspose1d of the reference: linear.go:117-182, conv1d.go:20-83, convtranspose1d.go:73-148)
+//
+// 64x64 block tile, 4 waves as 2x2, each wave one 32x32 accumulator of v_mfma_f32_32x32x2_f32
+// (exact f32 FMA chain -- the arithmetic the reference's f32 dot products perform, in a different
+// summation order).  K is walked in 32-deep tiles staged through LDS with 16-byte accesses; the
+// k index inside a tile is permuted consistently for both operands (lane half kq owns
+// k = 8*g + 4*kq + j), which lets each lane fetch its four values per operand with one ds_read_b128.
+// ------------------------------------------------------------------------------------------------
+constexpr int GM = 64, GN = 64, GK = 32, GLD = GK + 4;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <bool WBF16>
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) {
+    __shared__ __attribute__((aligned(16))) float As[GM * GLD];
+    __shared__ __attribute__((aligned(16))) float Ws[GN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * GM, n0 = blockIdx.x * GN;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging assignment: 2 x (row, c4) per thread for each operand
+    int srow[2], sc4[2];
+    const float* aptr[2];
+    const char* wptr[2];
+    bool arow_ok[2], wrow_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int idx = tid + i * 256;
+        srow[i] = idx >> 3;
+        sc4[i] = (idx & 7) * 4;
+        int gm = m0 + srow[i], gn = n0 + srow[i];
+        arow_ok[i] = gm < a.M;
+        wrow_ok[i] = gn < a.N;
+        aptr[i] = a.A + (arow_ok[i] ? row_off(a.amap, gm) : 0);
+        wptr[i] = (const char*)a.W + (wrow_ok[i] ? (int64_t)gn * a.ldw * (WBF16 ? 2 : 4) : 0);
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+
+    for (int k0 = 0; k0 < a.K; k0 += GK) {
+        float4 av[2], wv[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int k = k0 + sc4[i];
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (arow_ok[i]) {
+                if (a_vec && k + 3 < a.K) v = *reinterpret_cast<const float4*>(aptr[i] + k);
+                else {
+                    if (k + 0 < a.K) v.x = aptr[i][k + 0];
+                    if (k + 1 < a.K) v.y = aptr[i][k + 1];
+                    if (k + 2 < a.K) v.z = aptr[i][k + 2];
+                    if (k + 3 < a.K) v.w = aptr[i][k + 3];
+                }
+                if (a.aop == AOP_ELU) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+            }
+            av[i] = v;
+            float4 u = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (wrow_ok[i]) {
+                if (WBF16) {
+                    const unsigned short* wp = reinterpret_cast<const unsigned short*>(wptr[i]);
+                    if (w_vec && k + 3 < a.K) {
+                        uint2 raw = *reinterpret_cast<const uint2*>(wp + k);
+                        u.x = __uint_as_float(raw.x << 16); u.y = __uint_as_float(raw.x & 0xffff0000u);
+                        u.z = __uint_as_float(raw.y << 16); u.w = __uint_as_float(raw.y & 0xffff0000u);
+                    } else {
+                        if (k + 0 < a.K) u.x = bf16_bits_to_f32(wp[k + 0]);
+                        if (k + 1 < a.K) u.y = bf16_bits_to_f32(wp[k + 1]);
+                        if (k + 2 < a.K) u.z = bf16_bits_to_f32(wp[k + 2]);
+                        if (k + 3 < a.K) u.w = bf16_bits_to_f32(wp[k + 3]);
+                    }
+                } else {
+                    const float* wp = reinterpret_cast<const float*>(wptr[i]);
+                    if (w_vec && k + 3 < a.K) u = *reinterpret_cast<const float4*>(wp + k);
+                    else {
+                        if (k + 0 < a.K) u.x = wp[k + 0];
+                        if (k + 1 < a.K) u.y = wp[k + 1];
+                        if (k + 2 < a.K) u.z = wp[k + 2];
+                        if (k + 3 < a.K) u.w = wp[k + 3];
+                    }
+                }
+            }
+            wv[i] = u;
+        }
+        __syncthreads();  // previous tile fully consumed
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            *reinterpret_cast<float4*>(&As[srow[i] * GLD + sc4[i]]) = av[i];
+            *reinterpret_cast<float4*>(&Ws[srow[i] * GLD + sc4[i]]) = wv[i];
+        }
+        __syncthreads();
+        const int r = lane & 31, kq = lane >> 5;
+#pragma unroll
+        for (int g = 0; g < GK / 8; g++) {
+            float4 x4 = *reinterpret_cast<const float4*>(&As[(wm * 32 + r) * GLD + g * 8 + kq * 4]);
+            float4 w4 = *reinterpret_cast<const float4*>(&Ws[(wn * 32 + r) * GLD + g * 8 + kq * 4]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.x, w4.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.y, w4.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.z, w4.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4.w, w4.w, acc, 0, 0, 0);
+        }
+    }
+
+    // epilogue: lane holds C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of its 32x32 tile
+    const int n = n0 + wn * 32 + (lane & 31);
+    if (n >= a.N) return;
+    const float bias = a.bias ? a.bias[n] : 0.0f;
+    const float addv = a.addvec ? a.addvec[n] : 0.0f;
+    const float scl = a.scale ? a.scale[n] : 1.0f;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+        int m = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
+        if (m >= a.M) continue;
+        float v = acc[reg] + bias;
+        int64_t co = row_off(a.cmap, m) + n;
+        switch (a.epi) {
+            case EPI_NONE: break;
+            case EPI_GELU: v = gelu1(v); break;
+            case EPI_SILU: v = silu1(addv + v); break;
+            case EPI_ELU: v = elu1(v); break;
+            case EPI_RESADD: v = a.R[co] + v; break;
+            case EPI_SCALE_RESADD: v = a.R[co] + scl * v; break;
+            case EPI_GATE_RESADD: v = a.R[co] + a.gate[(int64_t)m * a.ldg + n] * v; break;
+            case EPI_AXPY: v = a.R[co] + a.alpha * v; break;
+        }
+        a.C[co] = v;
+    }
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+void launch_gemm(const GemmArgs& a, hipStream_t stream) {
+    if (a.M <= 0 || a.N <= 0) return;
+    int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;
+    int w_vec = a.w_bf16 ? ((reinterpret_cast<uintptr_t>(a.W) & 7) == 0 && a.ldw % 4 == 0) : (aligned16(a.W) && a.ldw % 4 == 0);
+    dim3 grid((a.N + GN - 1) / GN, (a.M + GM - 1) / GM);
+    if (a.w_bf16) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, stream, a, a_vec, w_vec);
+    else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, stream, a, a_vec, w_vec);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm (K3; linear.go:265-329 / nn_ops.go:79-149): one wave per row, mean and biased variance
+// accumulated in f64 exactly as the reference does, optional adaLN modulation fused (K11).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_layernorm(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.rows) return;
+    const float* x = a.x + row_off(a.xmap, row);
+    double s = 0.0;
+    for (int i = lane; i < a.d; i += WAVE) s += (double)x[i];
+    const double mean = wave_sum(s) / (double)a.d;
+    double v = 0.0;
+    for (int i = lane; i < a.d; i += WAVE) { double dlt = (double)x[i] - mean; v += dlt * dlt; }
+    const double var = wave_sum(v) / (double)a.d;
+    const float inv_std = (float)(1.0 / sqrt(var + (double)a.eps));
+    const float meanf = (float)mean;
+    float* y = a.y + (int64_t)row * a.ldy;
+    const float* sh = a.shift ? a.shift + (int64_t)row * a.ldmod : nullptr;
+    const float* sc = a.scale ? a.scale + (int64_t)row * a.ldmod : nullptr;
+    for (int i = lane; i < a.d; i += WAVE) {
+        float n = (x[i] - meanf) * inv_std;
+        if (a.w) n = n * a.w[i];
+        if (a.b) n = n + a.b[i];
+        if (sc) n = n * (sc[i] + 1.0f) + sh[i];
+        y[i] = n;
+    }
+}
+void launch_layernorm(const LnArgs& a, hipStream_t stream) {
+    if (a.rows <= 0) return;
+    hipLaunchKernelGGL(k_layernorm, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
+}
+
+__global__ __launch_bounds__(64) void k_rmsnorm_alpha(float* x, const float* alpha, float eps, int rows, int d) {
+    // tensor_util.go:273-326: unbiased variance about the mean, x itself is NOT centred
+    const int lane = threadIdx.x, row = blockIdx.x;
+    float* r = x + (int64_t)row * d;
+    double s = 0.0;
+    for (int i = lane; i < d; i += WAVE) s += (double)r[i];
+    const double mean = wave_sum(s) / (double)d;
+    double v = 0.0;
+    for (int i = lane; i < d; i += WAVE) { double dlt = (double)r[i] - mean; v += dlt * dlt; }
+    double var = wave_sum(v);
+    if (d > 1) var /= (double)(d - 1);
+    const float inv = (float)(1.0 / sqrt(var + (double)eps));
+    for (int i = lane; i < d; i += WAVE) r[i] = r[i] * inv * alpha[i];
+}
+void launch_rmsnorm_alpha(float* x, const float* alpha, float eps, int rows, int d, hipStream_t stream) {
+    hipLaunchKernelGGL(k_rmsnorm_alpha, dim3(rows), dim3(64), 0, stream, x, alpha, eps, rows, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise / gather kernels
+// ------------------------------------------------------------------------------------------------
+__global__ void k_embed_gather(const float* table, const int64_t* ids, int n, int d, float* out) {  // K1
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)n * (d / 4);
+    if (i >= tot) return;
+    int r = (int)(i / (d / 4)), c = (int)(i % (d / 4));
+    reinterpret_cast<float4*>(out + (int64_t)r * d)[c] = reinterpret_cast<const float4*>(table + ids[r] * (int64_t)d)[c];
+}
+void launch_embed_gather(const float* table, const int64_t* ids, int n, int d, float* out, hipStream_t stream) {
+    if (n <= 0) return;
+    int64_t tot = (int64_t)n * (d / 4);
+    hipLaunchKernelGGL(k_embed_gather, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, table, ids, n, d, out);
+}
+
+__global__ void k_replace_nan(const float* in, const float* bos, int rows, int d, float* out) {  // K2 (first half)
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * d) return;
+    float v = in[i];
+    out[i] = isnan(v) ? bos[i % d] : v;
+}
+void launch_replace_nan(const float* in, const float* bos, int rows, int d, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_replace_nan, dim3((rows * d + 255) / 256), dim3(256), 0, stream, in, bos, rows, d, out);
+}
+
+__global__ void k_silu(float* x, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] = silu1(x[i]);
+}
+void launch_silu(float* x, int64_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_silu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, n);
+}
+
+__global__ void k_copy_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int d) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)rows * d) return;
+    int r = (int)(i / d), c = (int)(i % d);
+    dst[(int64_t)r * ldd + c] = src[(int64_t)r * lds + c];
+}
+void launch_copy_rows(const float* src, int64_t lds, float* dst, int64_t ldd, int rows, int d, hipStream_t stream) {
+    int64_t n = (int64_t)rows * d;
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, src, lds, dst, ldd, rows, d);
+}
+
+__global__ void k_timestep_features(float t, const float* freqs, int nf, float* out) {  // flow_net.go:52-65
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nf) return;
+    float arg = t * freqs[i];
+    out[i] = (float)cos((double)arg);       // mimi.go:796-797: the reference evaluates cos/sin in f64
+    out[nf + i] = (float)sin((double)arg);
+}
+void launch_timestep_features(float t, const float* freqs, int nf, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(k_timestep_features, dim3((nf + 63) / 64), dim3(64), 0, stream, t, freqs, nf, out);
+}
+
+__global__ void k_avg2(const float* a, const float* b, float* y, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = (a[i] + b[i]) * 0.5f;
+}
+void launch_avg2(const float* a, const float* b, float* y, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_avg2, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, y, n);
+}
+
+__global__ void k_fill_i32(int32_t* p, int32_t v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_fill_i32, dim3((n + 255) / 256), dim3(256), 0, stream, p, v, n);
+}
+__global__ void k_add_i32(int32_t* p, const int32_t* inc, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += inc[i];
+}
+void launch_add_i32(int32_t* p, const int32_t* inc, int n, hipStream_t stream) {
+    hipLaunchKernelGGL(k_add_i32, dim3((n + 255) / 256), dim3(256), 0, stream, p, inc, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// RoPE on rows of a qkv buffer (K5; rope.go:81-105): interleaved pairs, table row = position
+// ------------------------------------------------------------------------------------------------
+__global__ void k_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, const int32_t* pos, int pos_base,
+                            int rows_per_seg, int rows, const float* cos_t, const float* sin_t) {
+    const int half = hd / 2;
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)rows * heads * half;
+    if (i >= tot) return;
+    int j = (int)(i % half);
+    int h = (int)((i / half) % heads);
+    int r = (int)(i / ((int64_t)half * heads));
+    int p = pos ? pos[r] : pos_base + (rows_per_seg ? r % rows_per_seg : r);
+    float* v = x + (int64_t)r * ld + col0 + h * hd + 2 * j;
+    float a = v[0], b = v[1];
+    float c = cos_t[(int64_t)p * half + j], s = sin_t[(int64_t)p * half + j];
+    v[0] = a * c - b * s;
+    v[1] = a * s + b * c;
+}
+void launch_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
+                      int rows, const float* cos_t, const float* sin_t, hipStream_t stream) {
+    int64_t tot = (int64_t)rows * heads * (hd / 2);
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(k_rope_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, x, ld, col0, heads, hd, pos,
+                       pos_base, rows_per_seg, rows, cos_t, sin_t);
+}
+
+// K6: append (already rotated) K and V rows into the cache [slot][head][cap][hd]  (flow_transformer.go:32-67)
+template <bool KVBF16>
+__global__ void k_kv_append(const float* qkv, int64_t ld, int d_model, int heads, int hd, const int32_t* row_slot,
+                            const int32_t* row_pos, int rows, void* kc, void* vc, int64_t cap) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)rows * d_model;
+    if (i >= tot) return;
+    int c = (int)(i % d_model), r = (int)(i / d_model);
+    int h = c / hd, e = c % hd;
+    int64_t dst = (((int64_t)row_slot[r] * heads + h) * cap + row_pos[r]) * hd + e;
+    float kv = qkv[(int64_t)r * ld + d_model + c], vv = qkv[(int64_t)r * ld + 2 * d_model + c];
+    if (KVBF16) {
+        reinterpret_cast<unsigned short*>(kc)[dst] = f32_to_bf16_bits(kv);
+        reinterpret_cast<unsigned short*>(vc)[dst] = f32_to_bf16_bits(vv);
+    } else {
+        reinterpret_cast<float*>(kc)[dst] = kv;
+        reinterpret_cast<float*>(vc)[dst] = vv;
+    }
+}
+void launch_kv_append(const float* qkv, int64_t ld, int d_model, int heads, int hd, const int32_t* row_slot,
+                      const int32_t* row_pos, int rows, void* kcache, void* vcache, int kv_bf16, int64_t cap,
+                      hipStream_t stream) {
+    int64_t tot = (int64_t)rows * d_model;
+    if (tot <= 0) return;
+    dim3 g((unsigned)((tot + 255) / 256));
+    if (kv_bf16) hipLaunchKernelGGL(k_kv_append<true>, g, dim3(256), 0, stream, qkv, ld, d_model, heads, hd, row_slot, row_pos, rows, kcache, vcache, cap);
+    else hipLaunchKernelGGL(k_kv_append<false>, g, dim3(256), 0, stream, qkv, ld, d_model, heads, hd, row_slot, row_pos, rows, kcache, vcache, cap);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention with absolute positions (K7; attention.go:307-484), head_dim 64.
+//   key j is visible to a query at position p iff 0 <= p - j (and p - j < context when context >= 0);
+//   cache slots beyond p are never read (the reference masks them with posK = -1 before the dot
+//   product, so NaN padding in voice-state caches cannot propagate); an empty key set gives zeros.
+// One query per (row, head).  WPQ waves cooperate on a query (4 for the latency-bound AR step,
+// 1 for prefill / Mimi where there are many queries).  Inside a wave 16 lanes share one key
+// (16 B each = one coalesced 256-byte f32 row or 128-byte bf16 row), 4 keys per wave-instruction.
+// Scores go through LDS once; softmax max/sum are wave reductions; P*V partials are combined in a
+// fixed order, so results are bitwise reproducible.
+// With fused_step the block first rotates q/k of its (slot, head) by the table row at the cache
+// offset and appends k, v at that offset (flow_transformer.go:340-347) -- K5 + K6 + K7 in one launch.
+// ------------------------------------------------------------------------------------------------
+template <bool KVBF16> __device__ __forceinline__ float4 load_kv4(const void* base, int64_t elem_off) {
+    if (KVBF16) {
+        uint2 raw = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
+        return make_float4(__uint_as_float(raw.x << 16), __uint_as_float(raw.x & 0xffff0000u), __uint_as_float(raw.y << 16),
+                           __uint_as_float(raw.y & 0xffff0000u));
+    }
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+}
+
+template <int WPQ, bool KVBF16>
+__global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int QPB = 4 / WPQ;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int qi = wave / WPQ, wq = wave % WPQ;          // query within block, wave within query
+    const int h = blockIdx.x;
+    const int row = blockIdx.y * QPB + qi;
+    const bool row_ok = row < a.rows;
+    float* sc = smem + (size_t)qi * a.max_keys;                          // scores of this query
+    float* part = smem + (size_t)QPB * a.max_keys + (size_t)qi * WPQ * 64;  // [WPQ][64] partial outputs
+    float* qs = smem + (size_t)QPB * a.max_keys + (size_t)QPB * WPQ * 64;   // [64] rotated q (fused step)
+
+    int seg = 0, pos = -1;
+    if (row_ok) {
+        seg = a.row_seg ? a.row_seg[row] : (a.rows_per_seg ? row / a.rows_per_seg : row);
+        pos = a.seg_len ? a.seg_len[seg] : (a.row_pos ? a.row_pos[row] : (a.rows_per_seg ? row % a.rows_per_seg : row));
+    }
+    const bool live = row_ok && (!a.active || a.active[seg]);
+    const char* kbase = (const char*)a.k + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * (KVBF16 ? 2 : 4);
+    const char* vbase = (const char*)a.v + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * (KVBF16 ? 2 : 4);
+
+    if (a.fused_step) {  // WPQ == 4, one query per block: uniform control flow
+        if (live) {
+            const float* qr = a.qkv + (int64_t)row * a.qkv_ld + h * 64;
+            if (tid < 32) {
+                float c = a.cos_t[(int64_t)pos * 32 + tid], s = a.sin_t[(int64_t)pos * 32 + tid];
+                float q0 = qr[2 * tid], q1 = qr[2 * tid + 1];
+                qs[2 * tid] = q0 * c - q1 * s;
+                qs[2 * tid + 1] = q0 * s + q1 * c;
+                float k0 = qr[a.d_model + 2 * tid], k1 = qr[a.d_model + 2 * tid + 1];
+                float r0 = k0 * c - k1 * s, r1 = k0 * s + k1 * c;
+                int64_t dst = (int64_t)pos * 64 + 2 * tid;
+                if (KVBF16) {
+                    reinterpret_cast<unsigned short*>(const_cast<char*>(kbase))[dst] = f32_to_bf16_bits(r0);
+                    reinterpret_cast<unsigned short*>(const_cast<char*>(kbase))[dst + 1] = f32_to_bf16_bits(r1);
+                } else {
+                    reinterpret_cast<float*>(const_cast<char*>(kbase))[dst] = r0;
+                    reinterpret_cast<float*>(const_cast<char*>(kbase))[dst + 1] = r1;
+                }
+            } else if (tid < 96) {
+                int e = tid - 32;
+                float vv = qr[2 * a.d_model + e];
+                int64_t dst = (int64_t)pos * 64 + e;
+                if (KVBF16) reinterpret_cast<unsigned short*>(const_cast<char*>(vbase))[dst] = f32_to_bf16_bits(vv);
+                else reinterpret_cast<float*>(const_cast<char*>(vbase))[dst] = vv;
+            }
+        }
+        __syncthreads();
+    }
+
+    int j0 = 0, nk = 0;
+    if (live) {
+        j0 = a.context >= 0 ? max(0, pos - a.context + 1) : 0;
+        nk = pos - j0 + 1;
+        if (nk < 0) nk = 0;
+    }
+    const int sub = lane & 15, kq = lane >> 4;
+    float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) {
+        if (a.fused_step) q4 = *reinterpret_cast<const float4*>(qs + sub * 4);
+        else q4 = *reinterpret_cast<const float4*>(a.q + (int64_t)row * a.q_ld + a.q_col0 + h * 64 + sub * 4);
+    }
+    const float scale = 0.125f;  // 1/sqrt(64)
+
+    // pass 1: scores
+    for (int base = wq * 4; base < nk; base += WPQ * 4) {
+        int jj = base + kq;
+        float p = 0.0f;
+        if (jj < nk) {
+            float4 k4 = load_kv4<KVBF16>(kbase, (int64_t)(j0 + jj) * a.k_row_stride + sub * 4);
+            p = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+        }
+        p += __shfl_xor(p, 8, WAVE);
+        p += __shfl_xor(p, 4, WAVE);
+        p += __shfl_xor(p, 2, WAVE);
+        p += __shfl_xor(p, 1, WAVE);
+        if (sub == 0 && jj < nk) sc[jj] = p * scale;
+    }
+    __syncthreads();
+    // softmax statistics (every wave of the query computes the same values)
+    float mx = -INFINITY;
+    for (int j = lane; j < nk; j += WAVE) mx = fmaxf(mx, sc[j]);
+    mx = wave_max(mx);
+    float sum = 0.0f;
+    for (int j = lane; j < nk; j += WAVE) sum += expf(sc[j] - mx);
+    sum = wave_sum(sum);
+    // pass 2: P * V
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int base = wq * 4; base < nk; base += WPQ * 4) {
+        int jj = base + kq;
+        if (jj < nk) {
+            float p = expf(sc[jj] - mx);
+            float4 v4 = load_kv4<KVBF16>(vbase, (int64_t)(j0 + jj) * a.k_row_stride + sub * 4);
+            o.x += p * v4.x; o.y += p * v4.y; o.z += p * v4.z; o.w += p * v4.w;
+        }
+    }
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        o.x += __shfl_xor(o.x, off, WAVE); o.y += __shfl_xor(o.y, off, WAVE);
+        o.z += __shfl_xor(o.z, off, WAVE); o.w += __shfl_xor(o.w, off, WAVE);
+    }
+    if (WPQ > 1) {
+        if (kq == 0) *reinterpret_cast<float4*>(part + wq * 64 + sub * 4) = o;
+        __syncthreads();
+        if (wq == 0 && kq == 0) {
+            o = *reinterpret_cast<const float4*>(part + sub * 4);
+#pragma unroll
+            for (int w = 1; w < WPQ; w++) {
+                float4 t = *reinterpret_cast<const float4*>(part + w * 64 + sub * 4);
+                o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+            }
+        }
+    }
+    if (row_ok && wq == 0 && kq == 0) {
+        float inv = (nk > 0 && sum > 0.0f) ? 1.0f / sum : 0.0f;
+        float4 r = nk > 0 ? make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(a.out + (int64_t)row * a.out_ld + h * 64 + sub * 4) = r;
+    }
+}
+
+void launch_attention(const AttnArgs& a, hipStream_t stream) {
+    if (a.rows <= 0) return;
+    const int wpq = a.fused_step ? 4 : (a.rows * a.heads < 2048 ? 4 : 1);
+    const int qpb = 4 / wpq;
+    size_t lds = ((size_t)qpb * a.max_keys + (size_t)qpb * wpq * 64 + 64) * sizeof(float);
+    dim3 grid(a.heads, (a.rows + qpb - 1) / qpb);
+    if (wpq == 4) {
+        if (a.kv_bf16) hipLaunchKernelGGL((k_attention<4, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((k_attention<4, false>), grid, dim3(256), lds, stream, a);
+    } else {
+        if (a.kv_bf16) hipLaunchKernelGGL((k_attention<1, true>), grid, dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((k_attention<1, false>), grid, dim3(256), lds, stream, a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mimi front end
+// ------------------------------------------------------------------------------------------------
+// K13: latent -> mimi projector with emb_std/emb_mean folded in (model.go:226-242,294-303)
+__global__ void k_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)b * (t + 1) * c;
+    if (i >= tot) return;
+    int oc = (int)(i % c);
+    int tt = (int)((i / c) % (t + 1));
+    int bi = (int)(i / ((int64_t)c * (t + 1)));
+    float v = 0.0f;
+    if (tt > 0) {
+        const float* l = latent + (int64_t)bi * lat_bstride + (int64_t)(tt - 1) * ldim;
+        const float* w = wp + (int64_t)oc * ldim;
+        float s = 0.0f;
+        for (int k = 0; k < ldim; k++) s += l[k] * w[k];
+        v = s + bp[oc];
+    }
+    out[i] = v;
+}
+void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c,
+                      float* out, hipStream_t stream) {
+    int64_t tot = (int64_t)b * (t + 1) * c;
+    hipLaunchKernelGGL(k_projector, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, latent, lat_bstride, wp, bp, b, t, ldim, c, out);
+}
+
+// K14: depthwise transposed conv, k = 2*stride, first T*stride outputs kept (convtranspose1d.go:154-202, mimi.go:116-125)
+__global__ void k_upsample_dw(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int c, int stride,
+                              float* out, int pad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)b * t * stride * c;
+    if (i >= tot) return;
+    int ch = (int)(i % c);
+    int r = (int)((i / c) % stride);
+    int tt = (int)((i / ((int64_t)c * stride)) % t);
+    int bi = (int)(i / ((int64_t)c * stride * t));
+    const float* x = in + ((int64_t)bi * (t + 1) + tt) * c + ch;  // x[0] = frame t-1 (row 0 is the zero row), x[c] = frame t
+    float prev = x[0] * w0[r * c + ch];
+    float cur = x[c] * w1[r * c + ch];
+    float v = prev + cur;
+    if (bias) v += bias[ch];
+    out[((int64_t)bi * (pad + (int64_t)t * stride) + pad + (int64_t)tt * stride + r) * c + ch] = v;
+}
+void launch_upsample_depthwise(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int c,
+                               int stride, float* out, int out_pad_rows, hipStream_t stream) {
+    int64_t tot = (int64_t)b * t * stride * c;
+    hipLaunchKernelGGL(k_upsample_dw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, w0, w1, bias, b, t, c, stride, out, out_pad_rows);
+}
+
+template <bool KVBF16>
+__global__ void k_voice_scatter(const float* raw, int t, int heads, int hd, int offset, int slot, void* kc, void* vc, int64_t cap) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t tot = (int64_t)offset * heads * hd;   // rows beyond `offset` hold NaN padding and are never read
+    if (i >= tot) return;
+    int e = (int)(i % hd);
+    int h = (int)((i / hd) % heads);
+    int step = (int)(i / ((int64_t)hd * heads));
+    float kv = raw[((int64_t)step * heads + h) * hd + e];                      // voiceKVIndex(0, ...)
+    float vv = raw[(((int64_t)t + step) * heads + h) * hd + e];                // voiceKVIndex(1, ...)
+    int64_t dst = (((int64_t)slot * heads + h) * cap + step) * hd + e;
+    if (KVBF16) {
+        reinterpret_cast<unsigned short*>(kc)[dst] = f32_to_bf16_bits(kv);
+        reinterpret_cast<unsigned short*>(vc)[dst] = f32_to_bf16_bits(vv);
+    } else {
+        reinterpret_cast<float*>(kc)[dst] = kv;
+        reinterpret_cast<float*>(vc)[dst] = vv;
+    }
+}
+void launch_voice_scatter(const float* raw, int t, int heads, int hd, int offset, int slot, void* kcache, void* vcache,
+                          int kv_bf16, int64_t cap, hipStream_t stream) {
+    int64_t tot = (int64_t)offset * heads * hd;
+    if (tot <= 0) return;
+    dim3 g((unsigned)((tot + 255) / 256));
+    if (kv_bf16) hipLaunchKernelGGL(k_voice_scatter<true>, g, dim3(256), 0, stream, raw, t, heads, hd, offset, slot, kcache, vcache, cap);
+    else hipLaunchKernelGGL(k_voice_scatter<false>, g, dim3(256), 0, stream, raw, t, heads, hd, offset, slot, kcache, vcache, cap);
+}
+
+// K16 (last layer): ELU then causal conv C -> 1 (mimi.go:781-783); window of k rows is one contiguous span
+__global__ void k_conv_final(const float* in, int pad, const float* w, const float* bias, int b, int t, int c, int k, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)b * t) return;
+    int tt = (int)(i % t), bi = (int)(i / t);
+    const float* x = in + ((int64_t)bi * (pad + t) + pad + tt - (k - 1)) * c;
+    float s = 0.0f;
+    int n = k * c;
+    for (int j = 0; j < n; j += 4) {
+        float4 v = *reinterpret_cast<const float4*>(x + j);
+        float4 ww = *reinterpret_cast<const float4*>(w + j);
+        s += elu1(v.x) * ww.x + elu1(v.y) * ww.y + elu1(v.z) * ww.z + elu1(v.w) * ww.w;
+    }
+    out[i] = s + (bias ? bias[0] : 0.0f);
+}
+void launch_conv_final(const float* in, int in_pad_rows, const float* w, const float* bias, int b, int t, int c, int k,
+                       float* out, hipStream_t stream) {
+    int64_t tot = (int64_t)b * t;
+    hipLaunchKernelGGL(k_conv_final, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, in_pad_rows, w, bias, b, t, c, k, out);
+}
+
+__global__ void k_zero_rows(float* base, int64_t batch_stride, int b, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)b * n) return;
+    base[(i / n) * batch_stride + (i % n)] = 0.0f;
+}
+void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipStream_t stream) {
+    int64_t tot = (int64_t)b * n;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(k_zero_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, base, batch_stride, b, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// AR-step bookkeeping: the per-utterance loop state of runtime_native_safetensors.go:150-201 on device
+// ------------------------------------------------------------------------------------------------
+__global__ void k_step_input(StepState s, const float* latents, int64_t lat_stride, const float* bos, int ldim, int b, float* in32) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * ldim) return;
+    int bi = i / ldim, e = i % ldim;
+    int st = s.step[bi];
+    float v = st == 0 ? NAN : latents[(int64_t)bi * lat_stride + (int64_t)(st - 1) * ldim + e];  // newBOSSequenceTensor :246-253
+    in32[i] = isnan(v) ? bos[e] : v;                                                              // replaceNaNWithVector
+}
+void launch_step_input(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, int ldim, int b,
+                       float* in32, hipStream_t stream) {
+    hipLaunchKernelGGL(k_step_input, dim3((b * ldim + 255) / 256), dim3(256), 0, stream, s, latents, lat_stride, bos, ldim, b, in32);
+}
+
+__global__ void k_step_noise(StepState s, const float* noise, int64_t noise_stride, int ldim, int b, float* x0) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b * ldim) return;
+    int bi = i / ldim, e = i % ldim;
+    x0[i] = noise ? noise[(int64_t)bi * noise_stride + (int64_t)s.step[bi] * ldim + e] : 0.0f;
+}
+void launch_step_noise(const StepState& s, const float* noise, int64_t noise_stride, int ldim, int b, float* x0,
+                       hipStream_t stream) {
+    hipLaunchKernelGGL(k_step_noise, dim3((b * ldim + 255) / 256), dim3(256), 0, stream, s, noise, noise_stride, ldim, b, x0);
+}
+
+__global__ void k_step_finish(StepState s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,
+                              int64_t lat_stride) {
+    int bi = blockIdx.x;
+    if (bi >= b) return;
+    if (!s.active[bi]) return;
+    int st = s.step[bi];
+    int e = threadIdx.x;
+    if (e < ldim) latents[(int64_t)bi * lat_stride + (int64_t)st * ldim + e] = frame[bi * ldim + e];  // latentFrames = append(...)
+    if (e == 0) {
+        bool is_eos = eos_logit[bi] > s.eos_threshold[bi];   // flow_lm.go:281
+        int cd = s.countdown[bi];
+        bool done = false;
+        if (is_eos && cd < 0) { cd = s.frames_after_eos[bi]; s.eos_step[bi] = st; }   // :178-182
+        if (cd >= 0) {                                                                // :184-190
+            if (cd == 0) { done = true; s.broke[bi] = 1; }
+            else cd--;
+        }
+        s.countdown[bi] = cd;
+        s.n_frames[bi] = st + 1;
+        s.step[bi] = st + 1;
+        s.kv_len[bi] += 1;
+        if (st + 1 >= s.max_steps[bi]) done = true;                                   // for step := range maxSteps
+        if (done) { s.active[bi] = 0; atomicSub(s.n_active, 1); }
+    }
+}
+void launch_step_finish(const StepState& s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,
+                        int64_t lat_stride, hipStream_t stream) {
+    hipLaunchKernelGGL(k_step_finish, dim3(b), dim3(64), 0, stream, s, frame, eos_logit, ldim, b, latents, lat_stride);
+}
+
+// ------------------------------------------------------------------------------------------------
+// layout helpers for the op-level entry points ([B, C, T] <-> channels-last with history rows)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_bct_to_btc(const float* in, int b, int c, int t, float* out, int pad) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)b * c * t) return;
+    int ch = (int)(i % c);
+    int tt = (int)((i / c) % t);
+    int bi = (int)(i / ((int64_t)c * t));
+    out[((int64_t)bi * (pad + t) + pad + tt) * c + ch] = in[((int64_t)bi * c + ch) * t + tt];
+}
+void launch_bct_to_btc(const float* in, int b, int c, int t, float* out, int out_pad_rows, hipStream_t stream) {
+    int64_t tot = (int64_t)b * c * t;
+    hipLaunchKernelGGL(k_bct_to_btc, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, b, c, t, out, out_pad_rows);
+}
+__global__ void k_btc_to_bct(const float* in, int pad, int b, int c, int t, float* out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)b * c * t) return;
+    int tt = (int)(i % t);
+    int ch = (int)((i / t) % c);
+    int bi = (int)(i / ((int64_t)c * t));
+    out[i] = in[((int64_t)bi * (pad + t) + pad + tt) * c + ch];
+}
+void launch_btc_to_bct(const float* in, int in_pad_rows, int b, int c, int t, float* out, hipStream_t stream) {
+    int64_t tot = (int64_t)b * c * t;
+    hipLaunchKernelGGL(k_btc_to_bct, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, in_pad_rows, b, c, t, out);
+}
+
+}  // namespace ptts

@@ -1,0 +1,350 @@
+// model.cpp -- checkpoint -> device arena.
+// Tensor names and optional/required rules follow the reference loaders:
+//   flow_lm.go:51-119, flow_transformer.go:110-156,482-511 (no biases loaded for in_proj/out_proj/
+//   linear1/linear2), flow_net.go:18-40,92-113,181-203,250-305, conditioner.go:17,
+//   mimi.go:44-67,86-114,180-239,546-637, model.go:176-250 (projector fold), var_builder.go.
+#include <cmath>
+#include <functional>
+
+#include "model.h"
+
+namespace ptts {
+namespace {
+
+struct Walker {
+    const StFile& f;
+    Desc& d;
+    bool bf16w;
+    uint8_t* host;  // null while planning
+    size_t cur = 0;
+
+    size_t reserve(size_t bytes) {
+        size_t off = (cur + 255) & ~(size_t)255;
+        cur = off + bytes;
+        return off;
+    }
+    bool has(const std::string& n) const { return f.has(n); }
+    const std::vector<int64_t>& shape(const std::string& n) const { return f.at(n).shape; }
+    std::vector<float> load(const std::string& n) const {
+        std::vector<float> v((size_t)f.at(n).count());
+        f.decode_f32(n, v.data());
+        return v;
+    }
+    // f32 vector item
+    size_t add_f32(size_t count, const std::function<void(float*)>& fill) {
+        size_t off = reserve(count * 4);
+        if (host) fill(reinterpret_cast<float*>(host + off));
+        return off;
+    }
+    // matrix item, stored f32 or bf16
+    size_t add_mat(size_t count, const std::function<void(float*)>& fill, int* is_bf16) {
+        *is_bf16 = bf16w ? 1 : 0;
+        size_t off = reserve(count * (bf16w ? 2 : 4));
+        if (host) {
+            if (bf16w) {
+                std::vector<float> tmp(count);
+                fill(tmp.data());
+                uint16_t* dst = reinterpret_cast<uint16_t*>(host + off);
+                for (size_t i = 0; i < count; i++) dst[i] = f32_to_bf16_rne(tmp[i]);
+            } else fill(reinterpret_cast<float*>(host + off));
+        }
+        d.n_params += (int64_t)count;
+        return off;
+    }
+    void expect_rank(const std::string& n, size_t rank) const {
+        if (shape(n).size() != rank) throw Error(PTTS_EFORMAT, strfmt("native: tensor \"%s\" rank %zu, want %zu", n.c_str(), shape(n).size(), rank));
+    }
+
+    Lin linear(const std::string& name, bool with_bias) {  // linear.go:18-45
+        Lin l;
+        const std::string wn = name + ".weight";
+        expect_rank(wn, 2);
+        l.out = (int)shape(wn)[0];
+        l.in = (int)shape(wn)[1];
+        l.w = add_mat((size_t)l.out * l.in, [&](float* dst) { f.decode_f32(wn, dst); }, &l.bf16);
+        if (with_bias && has(name + ".bias")) {
+            const std::string bn = name + ".bias";
+            if (shape(bn).size() != 1 || shape(bn)[0] != l.out) throw Error(PTTS_EFORMAT, strfmt("native: linear \"%s\" bias shape incompatible with weight", name.c_str()));
+            l.b = add_f32((size_t)l.out, [&](float* dst) { f.decode_f32(bn, dst); });
+        }
+        return l;
+    }
+    Norm norm(const std::string& name, float eps) {  // linear.go:191-207
+        Norm n;
+        const std::string wn = name + ".weight", bn = name + ".bias";
+        expect_rank(wn, 1);
+        expect_rank(bn, 1);
+        if (shape(wn)[0] != shape(bn)[0]) throw Error(PTTS_EFORMAT, strfmt("native: layernorm \"%s\" invalid shapes", name.c_str()));
+        n.d = (int)shape(wn)[0];
+        n.eps = eps;
+        n.w = add_f32((size_t)n.d, [&](float* dst) { f.decode_f32(wn, dst); });
+        n.b = add_f32((size_t)n.d, [&](float* dst) { f.decode_f32(bn, dst); });
+        d.n_params += 2 * n.d;
+        return n;
+    }
+    // Conv1d [Cout, Cin, k] -> GEMM operand [Cout][kx*Cin + ic] for channels-last windows (conv1d.go:86-88)
+    Lin conv_as_gemm(const std::string& name, int* k_out, int* cin_out) {
+        Lin l;
+        const std::string wn = name + ".weight";
+        expect_rank(wn, 3);
+        int oc = (int)shape(wn)[0], ic = (int)shape(wn)[1], k = (int)shape(wn)[2];
+        *k_out = k;
+        *cin_out = ic;
+        l.out = oc;
+        l.in = ic * k;
+        l.w = add_mat((size_t)oc * ic * k, [&](float* dst) {
+            std::vector<float> w = load(wn);
+            for (int o = 0; o < oc; o++)
+                for (int c = 0; c < ic; c++)
+                    for (int x = 0; x < k; x++) dst[(size_t)o * ic * k + (size_t)x * ic + c] = w[((size_t)o * ic + c) * k + x];
+        }, &l.bf16);
+        if (has(name + ".bias")) l.b = add_f32((size_t)oc, [&](float* dst) { f.decode_f32(name + ".bias", dst); });
+        return l;
+    }
+    // ConvTranspose1d [Cin, Cout, k=2s], first L*s outputs kept (mimi.go:116-125): out[t*s + r, oc] =
+    //   sum_ic x[t-1, ic] * W[ic, oc, r + s] + x[t, ic] * W[ic, oc, r]   -> GEMM operand [(r, oc)][(j, ic)], j = 0: x[t-1], 1: x[t]
+    Lin convtr_as_gemm(const std::string& name, int stride, int* cin_out, int* cout_out) {
+        Lin l;
+        const std::string wn = name + ".weight";
+        expect_rank(wn, 3);
+        int ic = (int)shape(wn)[0], oc = (int)shape(wn)[1], k = (int)shape(wn)[2];
+        if (k != 2 * stride) throw Error(PTTS_EFORMAT, strfmt("native: convtranspose \"%s\" kernel %d, this build needs kernel = 2*stride = %d", name.c_str(), k, 2 * stride));
+        *cin_out = ic;
+        *cout_out = oc;
+        l.out = stride * oc;
+        l.in = 2 * ic;
+        l.w = add_mat((size_t)l.out * l.in, [&](float* dst) {
+            std::vector<float> w = load(wn);
+            for (int r = 0; r < stride; r++)
+                for (int o = 0; o < oc; o++)
+                    for (int c = 0; c < ic; c++) {
+                        size_t row = (size_t)r * oc + o;
+                        dst[row * 2 * ic + c] = w[((size_t)c * oc + o) * k + r + stride];
+                        dst[row * 2 * ic + ic + c] = w[((size_t)c * oc + o) * k + r];
+                    }
+        }, &l.bf16);
+        if (has(name + ".bias"))
+            l.b = add_f32((size_t)l.out, [&](float* dst) {
+                std::vector<float> b = load(name + ".bias");
+                for (int r = 0; r < stride; r++)
+                    for (int o = 0; o < oc; o++) dst[(size_t)r * oc + o] = b[o];
+            });
+        return l;
+    }
+
+    void rope_tables(int hd, double max_period, size_t* cos_off, size_t* sin_off) {  // flow_transformer.go:797-832
+        int half = hd / 2;
+        auto gen = [&](bool want_cos) {
+            return [=](float* dst) {
+                std::vector<double> inv((size_t)half);
+                for (int i = 0; i < half; i++) inv[i] = 1.0 / std::pow(max_period, (double)i / (double)half);
+                for (int pos = 0; pos < ROPE_SEQ; pos++)
+                    for (int i = 0; i < half; i++) {
+                        double ang = (double)pos * inv[i];
+                        dst[(size_t)pos * half + i] = (float)(want_cos ? std::cos(ang) : std::sin(ang));
+                    }
+            };
+        };
+        *cos_off = add_f32((size_t)ROPE_SEQ * half, gen(true));
+        *sin_off = add_f32((size_t)ROPE_SEQ * half, gen(false));
+    }
+
+    void run() {
+        d.n_params = 0;
+        // ---------------- flow_lm ----------------
+        const std::string fl = "flow_lm.";
+        const std::string en = fl + "conditioner.embed.weight";
+        expect_rank(en, 2);
+        d.n_bins = (int)shape(en)[0];
+        d.d_model = (int)shape(en)[1];
+        d.embed = add_f32((size_t)d.n_bins * d.d_model, [&](float* dst) { f.decode_f32(en, dst); });
+        d.n_params += (int64_t)d.n_bins * d.d_model;
+        d.n_layers = 0;
+        for (int i = 0; i < MAX_LAYERS; i++) {
+            std::string p = fl + "transformer.layers." + std::to_string(i);
+            if (!has(p + ".norm1.weight")) break;
+            auto& L = d.layers[i];
+            L.n1 = norm(p + ".norm1", 1e-5f);
+            L.n2 = norm(p + ".norm2", 1e-5f);
+            L.in_proj = linear(p + ".self_attn.in_proj", false);
+            L.out_proj = linear(p + ".self_attn.out_proj", false);
+            L.l1 = linear(p + ".linear1", false);
+            L.l2 = linear(p + ".linear2", false);
+            if (L.out_proj.out % d.heads) throw Error(PTTS_EFORMAT, strfmt("native: d_model %d not divisible by num_heads %d", L.out_proj.out, d.heads));
+            d.n_layers++;
+        }
+        if (d.n_layers == 0) throw Error(PTTS_EFORMAT, "native: no flow_lm transformer layers found");
+        d.hd = d.layers[0].out_proj.out / d.heads;
+        d.ffn = d.layers[0].l1.out;
+        if (d.hd != 64) throw Error(PTTS_EINVAL, strfmt("ptts-hip: flow head_dim %d unsupported (kernels are built for 64)", d.hd));
+        rope_tables(d.hd, 10000.0, &d.rope_cos, &d.rope_sin);
+        for (const char* nm : {"emb_std", "emb_mean", "bos_emb"}) {
+            expect_rank(fl + nm, 1);
+            if (shape(fl + nm)[0] != d.ldim) throw Error(PTTS_EFORMAT, strfmt("native varbuilder: tensor \"flow_lm.%s\" shape does not match expected [%d]", nm, d.ldim));
+        }
+        d.bos = add_f32((size_t)d.ldim, [&](float* dst) { f.decode_f32(fl + "bos_emb", dst); });
+        d.input_linear = linear(fl + "input_linear", true);
+        d.out_norm = norm(fl + "out_norm", 1e-5f);
+        d.out_eos = linear(fl + "out_eos", true);
+        // ---------------- flow_net ----------------
+        const std::string fn = fl + "flow_net.";
+        for (int i = 0; i < 2; i++) {
+            std::string p = fn + "time_embed." + std::to_string(i);
+            auto& te = d.te[i];
+            d.nfreq = (int)f.at(p + ".freqs").count();
+            te.freqs = add_f32((size_t)d.nfreq, [&](float* dst) { f.decode_f32(p + ".freqs", dst); });
+            te.l1 = linear(p + ".mlp.0", true);
+            te.l2 = linear(p + ".mlp.2", true);
+            te.alpha = add_f32((size_t)f.at(p + ".mlp.3.alpha").count(), [&](float* dst) { f.decode_f32(p + ".mlp.3.alpha", dst); });
+        }
+        d.cond_embed = linear(fn + "cond_embed", true);
+        d.input_proj = linear(fn + "input_proj", true);
+        d.flow_dim = d.input_proj.out;
+        d.flow_depth = 0;
+        for (int i = 0; i < MAX_LAYERS; i++) {
+            std::string p = fn + "res_blocks." + std::to_string(i);
+            if (!has(p + ".in_ln.weight")) break;
+            auto& rb = d.rb[i];
+            rb.ln = norm(p + ".in_ln", 1e-6f);
+            rb.mlp0 = linear(p + ".mlp.0", true);
+            rb.mlp2 = linear(p + ".mlp.2", true);
+            d.flow_depth++;
+        }
+        if (d.flow_depth == 0) throw Error(PTTS_EFORMAT, "native: no flow_net res blocks found");
+        {
+            // every adaLN matrix consumes silu(y) only (flow_net.go:117,206), so the depth*3C + 2C output rows are
+            // stacked into one [N, C] operand: one weight stream instead of depth+1 small dependent launches
+            const int C = d.flow_dim;
+            std::vector<std::string> names;
+            for (int i = 0; i < d.flow_depth; i++) names.push_back(fn + "res_blocks." + std::to_string(i) + ".adaLN_modulation.1");
+            names.push_back(fn + "final_layer.adaLN_modulation.1");
+            int rows = 0;
+            for (auto& n : names) {
+                expect_rank(n + ".weight", 2);
+                if (shape(n + ".weight")[1] != C) throw Error(PTTS_EFORMAT, strfmt("native: \"%s\" input width mismatch", n.c_str()));
+                rows += (int)shape(n + ".weight")[0];
+            }
+            d.ada_all.out = rows;
+            d.ada_all.in = C;
+            d.ada_all.w = add_mat((size_t)rows * C, [&](float* dst) {
+                size_t o = 0;
+                for (auto& n : names) { f.decode_f32(n + ".weight", dst + o); o += (size_t)f.at(n + ".weight").count(); }
+            }, &d.ada_all.bf16);
+            d.ada_all.b = add_f32((size_t)rows, [&](float* dst) {
+                size_t o = 0;
+                for (auto& n : names) {
+                    size_t cnt = (size_t)shape(n + ".weight")[0];
+                    if (has(n + ".bias")) f.decode_f32(n + ".bias", dst + o);
+                    else std::fill(dst + o, dst + o + cnt, 0.0f);
+                    o += cnt;
+                }
+            });
+        }
+        d.final_linear = linear(fn + "final_layer.linear", true);
+        // ---------------- mimi ----------------
+        const std::string mi = "mimi.";
+        {
+            const std::string qn = mi + "quantizer.output_proj.weight";
+            expect_rank(qn, 3);
+            int oc = (int)shape(qn)[0], ic = (int)shape(qn)[1], k = (int)shape(qn)[2];
+            if (k != 1 || ic != d.ldim) throw Error(PTTS_EFORMAT, "native: quantizer projection must be a 1x1 conv over the latent dim");
+            d.mimi_dim = oc;
+            // model.go:226-242: W'[oc,ic] = W[oc,ic]*std[ic]; b'[oc] = b[oc] + sum_ic W[oc,ic]*mean[ic] (sequential f32)
+            auto fold = [&](std::vector<float>& wf, std::vector<float>& bf) {
+                std::vector<float> w = load(qn), sd = load(fl + "emb_std"), mn = load(fl + "emb_mean");
+                std::vector<float> braw;
+                if (has(mi + "quantizer.output_proj.bias")) braw = load(mi + "quantizer.output_proj.bias");
+                wf.resize((size_t)oc * ic);
+                bf.resize((size_t)oc);
+                for (int o = 0; o < oc; o++) {
+                    float bv = braw.empty() ? 0.0f : braw[o];
+                    for (int c = 0; c < ic; c++) {
+                        float wv = w[(size_t)o * ic + c];
+                        wf[(size_t)o * ic + c] = wv * sd[c];
+                        float t = wv * mn[c];
+                        bv = bv + t;
+                    }
+                    bf[o] = bv;
+                }
+            };
+            d.proj_w = add_f32((size_t)oc * ic, [&](float* dst) { std::vector<float> wf, bf; fold(wf, bf); std::copy(wf.begin(), wf.end(), dst); });
+            d.proj_b = add_f32((size_t)oc, [&](float* dst) { std::vector<float> wf, bf; fold(wf, bf); std::copy(bf.begin(), bf.end(), dst); });
+            d.n_params += (int64_t)oc * ic;
+        }
+        {
+            const std::string un = mi + "upsample.convtr.convtr.weight";  // [C, 1, k], groups = C (mimi.go:567)
+            expect_rank(un, 3);
+            int c = (int)shape(un)[0], opg = (int)shape(un)[1], k = (int)shape(un)[2];
+            if (c != d.mimi_dim || opg != 1 || k != 2 * d.up_stride)
+                throw Error(PTTS_EFORMAT, strfmt("native: upsample convtr shape [%d,%d,%d], want depthwise [%d,1,%d]", c, opg, k, d.mimi_dim, 2 * d.up_stride));
+            d.up_k = k;
+            const int s = d.up_stride;
+            d.up_w0 = add_f32((size_t)s * c, [&](float* dst) { std::vector<float> w = load(un); for (int r = 0; r < s; r++) for (int ch = 0; ch < c; ch++) dst[(size_t)r * c + ch] = w[(size_t)ch * k + r + s]; });
+            d.up_w1 = add_f32((size_t)s * c, [&](float* dst) { std::vector<float> w = load(un); for (int r = 0; r < s; r++) for (int ch = 0; ch < c; ch++) dst[(size_t)r * c + ch] = w[(size_t)ch * k + r]; });
+            d.n_params += (int64_t)c * k;
+        }
+        d.mimi_layers = 0;
+        for (int i = 0; i < MAX_LAYERS; i++) {
+            std::string p = mi + "decoder_transformer.transformer.layers." + std::to_string(i);
+            if (!has(p + ".norm1.weight")) break;
+            auto& L = d.ml[i];
+            L.n1 = norm(p + ".norm1", 1e-5f);
+            L.n2 = norm(p + ".norm2", 1e-5f);
+            L.in_proj = linear(p + ".self_attn.in_proj", false);
+            L.out_proj = linear(p + ".self_attn.out_proj", false);
+            L.l1 = linear(p + ".linear1", false);
+            L.l2 = linear(p + ".linear2", false);
+            if (has(p + ".layer_scale_1.scale")) L.ls1 = add_f32((size_t)f.at(p + ".layer_scale_1.scale").count(), [&](float* dst) { f.decode_f32(p + ".layer_scale_1.scale", dst); });
+            if (has(p + ".layer_scale_2.scale")) L.ls2 = add_f32((size_t)f.at(p + ".layer_scale_2.scale").count(), [&](float* dst) { f.decode_f32(p + ".layer_scale_2.scale", dst); });
+            if (L.out_proj.out % d.mimi_heads) throw Error(PTTS_EFORMAT, strfmt("native: mimi d_model %d not divisible by heads %d", L.out_proj.out, d.mimi_heads));
+            d.mimi_layers++;
+        }
+        if (d.mimi_layers == 0) throw Error(PTTS_EFORMAT, "native: no mimi decoder transformer layers found");
+        d.mimi_hd = d.ml[0].out_proj.out / d.mimi_heads;
+        d.mimi_ffn = d.ml[0].l1.out;
+        if (d.mimi_hd != 64 || d.ml[0].out_proj.out != d.mimi_dim) throw Error(PTTS_EINVAL, strfmt("ptts-hip: mimi head_dim %d unsupported (kernels are built for 64)", d.mimi_hd));
+        int cin = 0, cout = 0;
+        d.init_conv = conv_as_gemm(mi + "decoder.model.0.conv", &d.init_k, &cin);
+        if (cin != d.mimi_dim) throw Error(PTTS_EFORMAT, "native: decoder initConv input channels mismatch");
+        d.sea_ch[0] = d.init_conv.out;
+        static const int up_idx[3] = {2, 5, 8}, rb_idx[3] = {3, 6, 9};
+        for (int j = 0; j < 3; j++) {
+            d.up[j] = convtr_as_gemm(mi + "decoder.model." + std::to_string(up_idx[j]) + ".convtr", d.strides[j], &cin, &cout);
+            if (cin != d.sea_ch[j]) throw Error(PTTS_EFORMAT, "native: decoder convtr input channels mismatch");
+            d.sea_ch[j + 1] = cout;
+            int c1 = 0, c2 = 0;
+            d.rb1[j] = conv_as_gemm(mi + "decoder.model." + std::to_string(rb_idx[j]) + ".block.1.conv", &d.rb_k1[j], &c1);
+            d.rb2[j] = conv_as_gemm(mi + "decoder.model." + std::to_string(rb_idx[j]) + ".block.3.conv", &d.rb_k2[j], &c2);
+            d.sea_hidden[j] = d.rb1[j].out;
+            if (c1 != cout || c2 != d.sea_hidden[j] || d.rb2[j].out != cout) throw Error(PTTS_EFORMAT, "native: SEANet residual block channel mismatch");
+        }
+        {
+            const std::string cn = mi + "decoder.model.11.conv";
+            expect_rank(cn + ".weight", 3);
+            int oc = (int)shape(cn + ".weight")[0], ic = (int)shape(cn + ".weight")[1], k = (int)shape(cn + ".weight")[2];
+            if (oc != 1 || ic != d.sea_ch[3]) throw Error(PTTS_EFORMAT, "native: final conv must map the last SEANet width to 1 channel");
+            d.final_k = k;
+            d.final_w = add_f32((size_t)ic * k, [&](float* dst) { std::vector<float> w = load(cn + ".weight"); for (int c = 0; c < ic; c++) for (int x = 0; x < k; x++) dst[(size_t)x * ic + c] = w[(size_t)c * k + x]; });
+            if (has(cn + ".bias")) d.final_b = add_f32(1, [&](float* dst) { f.decode_f32(cn + ".bias", dst); });
+            d.n_params += (int64_t)ic * k;
+        }
+        d.samples_per_frame = (int64_t)d.up_stride * d.strides[0] * d.strides[1] * d.strides[2];
+        d.total_bytes = (cur + 255) & ~(size_t)255;
+    }
+};
+
+}  // namespace
+
+void plan_build(Plan& p) {
+    Walker w{p.file, p.desc, p.opts.weights == PTTS_WEIGHTS_BF16, nullptr};
+    w.run();
+}
+
+void plan_fill(const Plan& p, uint8_t* host) {
+    Desc scratch = p.desc;
+    Walker w{p.file, scratch, p.opts.weights == PTTS_WEIGHTS_BF16, host};
+    w.run();
+    if (scratch.total_bytes != p.desc.total_bytes) throw Error(PTTS_EFORMAT, "ptts-hip: arena layout changed between plan and fill");
+}
+
+}  // namespace ptts

@@ -1,0 +1,65 @@
+// model.h -- device-resident model: one contiguous HBM arena + a table of offsets.
+//
+// The arena holds every tensor in the layout the kernels stream it in (weights [out, in]
+// row-major in f32 or bf16, convolution kernels repacked as GEMM operands for channels-last
+// activations, emb_std/emb_mean folded into the latent->mimi projection, RoPE tables, the
+// concatenated adaLN matrix).  Because it is one block whose layout depends on the file
+// header alone, it can be filled by one rank and broadcast once over RCCL.
+#pragma once
+
+#include "common.h"
+
+namespace ptts {
+
+constexpr size_t NONE = (size_t)-1;
+constexpr int MAX_LAYERS = 32;
+constexpr int ROPE_SEQ = 8192;  // flow_transformer.go:505, mimi.go:498
+
+struct Lin {   // linear.go:11-16 (also a convolution expressed as a GEMM)
+    size_t w = NONE, b = NONE;
+    int in = 0, out = 0, bf16 = 0;
+};
+struct Norm {  // linear.go:184-189
+    size_t w = NONE, b = NONE;
+    int d = 0;
+    float eps = 1e-5f;
+};
+
+struct Desc {
+    // flow_lm (flow_lm.go:13-43)
+    int d_model = 0, heads = 16, hd = 0, n_layers = 0, ffn = 0, ldim = 32, n_bins = 0;
+    size_t embed = NONE, bos = NONE, rope_cos = NONE, rope_sin = NONE;
+    Lin input_linear, out_eos;
+    Norm out_norm;
+    struct Layer { Norm n1, n2; Lin in_proj, out_proj, l1, l2; } layers[MAX_LAYERS];
+    // flow_net (flow_net.go:242-248)
+    int flow_dim = 0, flow_depth = 0, nfreq = 0;
+    struct TE { size_t freqs = NONE, alpha = NONE; Lin l1, l2; } te[2];
+    Lin cond_embed, input_proj, ada_all, final_linear;
+    struct RB { Norm ln; Lin mlp0, mlp2; } rb[MAX_LAYERS];
+    // mimi (mimi.go:16-34,528-544)
+    int mimi_dim = 0, mimi_heads = 8, mimi_hd = 0, mimi_layers = 0, mimi_ffn = 0, mimi_ctx = 250;
+    int up_stride = 16, up_k = 32;
+    size_t proj_w = NONE, proj_b = NONE, up_w0 = NONE, up_w1 = NONE;
+    struct ML { Norm n1, n2; Lin in_proj, out_proj, l1, l2; size_t ls1 = NONE, ls2 = NONE; } ml[MAX_LAYERS];
+    int sea_ch[4] = {0, 0, 0, 0};        // channels after initConv, up1, up2, up3
+    int sea_hidden[3] = {0, 0, 0};
+    int strides[3] = {6, 5, 4};          // mimi.go:582,592,602
+    int init_k = 0, rb_k1[3] = {0, 0, 0}, rb_k2[3] = {0, 0, 0}, final_k = 0;
+    Lin init_conv, up[3], rb1[3], rb2[3];
+    size_t final_w = NONE, final_b = NONE;
+    int64_t samples_per_frame = 0;
+    int64_t n_params = 0;
+    size_t total_bytes = 0;
+};
+
+struct Plan {
+    StFile file;
+    ptts_opts opts;
+    Desc desc;
+};
+
+void plan_build(Plan& p);                       // header -> Desc + arena layout
+void plan_fill(const Plan& p, uint8_t* host);   // decode / convert / derive into a host image of the arena
+
+}  // namespace ptts

@@ -1,0 +1,702 @@
+// runtime.cpp -- engine: model open, FlowLM batch state, prefill, AR step, Mimi decode, GenerateAudio.
+// Reference call path being replaced: internal/tts/runtime_native_safetensors.go:52-238 ->
+// internal/native/{model,flow_lm,flow_transformer,flow_net,mimi}.go.
+#include "runtime.h"
+
+#include <algorithm>
+#include <cmath>
+
+namespace ptts {
+
+static RowMap flat(int64_t ld) { return RowMap{ld, 0, 0}; }
+static RowMap seg(int64_t ld, int64_t rows_per_batch, int64_t batch_stride) { return RowMap{ld, rows_per_batch, batch_stride}; }
+
+static GemmArgs mk(const Model& m, const float* A, RowMap am, const Lin& l, float* C, RowMap cm, int M) {
+    GemmArgs g;
+    g.A = A; g.amap = am;
+    g.W = m.arena + l.w; g.w_bf16 = l.bf16; g.ldw = l.in;
+    g.bias = m.at<float>(l.b);
+    g.C = C; g.cmap = cm;
+    g.M = M; g.N = l.out; g.K = l.in;
+    return g;
+}
+static LnArgs mkln(const Model& m, const float* x, RowMap xm, const Norm& n, float* y, int64_t ldy, int rows) {
+    LnArgs a;
+    a.x = x; a.xmap = xm;
+    a.w = m.at<float>(n.w); a.b = m.at<float>(n.b);
+    a.eps = n.eps;
+    a.y = y; a.ldy = ldy;
+    a.rows = rows; a.d = n.d;
+    return a;
+}
+
+static void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    PTTS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
+    PTTS_HIP(hipStreamSynchronize(s));
+}
+static void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
+    if (!bytes) return;
+    PTTS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    PTTS_HIP(hipStreamSynchronize(s));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Model
+// ------------------------------------------------------------------------------------------------
+Model::~Model() {
+    cached_batch.reset();
+    tcomb.clear();
+    ws.clear();
+    if (own_arena && arena) (void)hipFree(arena);
+    if (stream) (void)hipStreamDestroy(stream);
+}
+
+Model* model_open(Plan* plan, void* device_arena, int fill) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        throw Error(PTTS_ENODEVICE, "ptts-hip: no HIP device available (this library has no CPU fallback)");
+    if (plan->opts.device < 0 || plan->opts.device >= ndev)
+        throw Error(PTTS_ENODEVICE, strfmt("ptts-hip: device %d out of range (%d visible)", plan->opts.device, ndev));
+    std::unique_ptr<Model> m(new Model());
+    m->d = plan->desc;
+    m->opts = plan->opts;
+    m->device = plan->opts.device;
+    m->use_device();
+    PTTS_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    if (device_arena) {
+        m->arena = reinterpret_cast<uint8_t*>(device_arena);
+    } else {
+        void* p = nullptr;
+        PTTS_HIP(hipMalloc(&p, m->d.total_bytes));
+        m->arena = reinterpret_cast<uint8_t*>(p);
+        m->own_arena = true;
+        fill = 1;
+    }
+    if (fill) {
+        std::vector<uint8_t> host(m->d.total_bytes, 0);
+        plan_fill(*plan, host.data());
+        PTTS_HIP(hipMemcpy(m->arena, host.data(), host.size(), hipMemcpyHostToDevice));
+    }
+    return m.release();
+}
+
+// timestep embedder (flow_net.go:42-83) for one (s, t) pair, then 0.5*(e_s + e_t) (flow_net.go:320-335)
+void Model::compute_tcomb(float sv, float tv, float* dst) {
+    const int C = d.flow_dim, nf = d.nfreq;
+    DevBuf& wsb = work(0, (size_t)(2 * nf + 3 * C) * sizeof(float));
+    float* feat = wsb.as<float>();
+    float* h = feat + 2 * nf;
+    float* e[2] = {h + C, h + 2 * C};
+    const float tvals[2] = {sv, tv};
+    for (int i = 0; i < 2; i++) {
+        const auto& te = d.te[i];
+        if (te.l1.in != 2 * nf) throw Error(PTTS_EFORMAT, "native: timestep embedder width mismatch");
+        launch_timestep_features(tvals[i], at<float>(te.freqs), nf, feat, stream);
+        GemmArgs g1 = mk(*this, feat, flat(2 * nf), te.l1, h, flat(C), 1);
+        g1.epi = EPI_SILU;
+        launch_gemm(g1, stream);
+        GemmArgs g2 = mk(*this, h, flat(C), te.l2, e[i], flat(C), 1);
+        launch_gemm(g2, stream);
+        launch_rmsnorm_alpha(e[i], at<float>(te.alpha), 1e-5f, 1, C, stream);
+    }
+    launch_avg2(e[0], e[1], dst, C, stream);
+}
+
+const float* Model::tcomb_for(int n) {
+    auto it = tcomb.find(n);
+    if (it != tcomb.end()) return it->second->as<float>();
+    std::unique_ptr<DevBuf> buf(new DevBuf());
+    buf->ensure((size_t)n * d.flow_dim * sizeof(float));
+    for (int i = 0; i < n; i++)  // flow_lm.go:325-329: s = i/n, t = (i+1)/n in float32
+        compute_tcomb((float)i / (float)n, (float)(i + 1) / (float)n, buf->as<float>() + (size_t)i * d.flow_dim);
+    PTTS_HIP(hipStreamSynchronize(stream));
+    const float* p = buf->as<float>();
+    tcomb[n] = std::move(buf);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Batch
+// ------------------------------------------------------------------------------------------------
+Batch::~Batch() {
+    if (graph) (void)hipGraphExecDestroy(graph);
+    if (n_active_pinned) (void)hipHostFree(n_active_pinned);
+}
+
+Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
+    if (n_slots <= 0) throw Error(PTTS_EINVAL, "ptts-hip: batch needs at least one slot");
+    if (cap <= 0 || cap > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ptts-hip: kv capacity %d outside (0, %d] (RoPE table rows, flow_transformer.go:505)", cap, ROPE_SEQ));
+    m.use_device();
+    const Desc& d = m.d;
+    std::unique_ptr<Batch> b(new Batch());
+    b->m = &m;
+    b->B = n_slots;
+    b->cap = cap;
+    b->max_steps = std::max(1, max_steps);
+    const size_t B = (size_t)n_slots;
+    size_t kvbytes = (size_t)d.n_layers * B * d.heads * cap * d.hd * b->kv_elem();
+    b->kcache.ensure(kvbytes);
+    b->vcache.ensure(kvbytes);
+    b->state_i32.ensure((9 * B + 1) * sizeof(int32_t));
+    b->state_f32.ensure(B * sizeof(float));
+    int32_t* s = b->state_i32.as<int32_t>();
+    b->st.kv_len = s; b->st.active = s + B; b->st.step = s + 2 * B; b->st.countdown = s + 3 * B;
+    b->st.n_frames = s + 4 * B; b->st.eos_step = s + 5 * B; b->st.max_steps = s + 6 * B;
+    b->st.frames_after_eos = s + 7 * B; b->st.broke = s + 8 * B; b->st.n_active = s + 9 * B;
+    b->st.eos_threshold = b->state_f32.as<float>();
+    b->kv_len_host.assign(B, 0);
+    const size_t f = sizeof(float);
+    const int NA = d.ada_all.out;
+    b->in_raw.ensure(B * d.ldim * f); b->in32.ensure(B * d.ldim * f);
+    b->x.ensure(B * d.d_model * f); b->xn.ensure(B * d.d_model * f);
+    b->qkv.ensure(B * 3 * d.d_model * f); b->attn.ensure(B * d.d_model * f);
+    b->ff.ensure(B * d.ffn * f); b->last.ensure(B * d.d_model * f); b->eos.ensure(B * f);
+    b->sy.ensure(B * d.flow_dim * f); b->ada.ensure(B * NA * f);
+    b->fx.ensure(B * d.flow_dim * f); b->fh.ensure(B * d.flow_dim * f); b->fh2.ensure(B * d.flow_dim * f);
+    b->cur.ensure(B * d.ldim * f);
+    b->latents.ensure(B * b->max_steps * d.ldim * f);
+    PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t), hipHostMallocDefault));
+    batch_reset(*b);
+    return b.release();
+}
+
+void batch_reset(Batch& b) {
+    hipStream_t s = b.m->stream;
+    const int B = b.B;
+    launch_fill_i32(b.st.kv_len, 0, B, s);
+    launch_fill_i32(b.st.active, 1, B, s);
+    launch_fill_i32(b.st.step, 0, B, s);
+    launch_fill_i32(b.st.countdown, -1, B, s);
+    launch_fill_i32(b.st.n_frames, 0, B, s);
+    launch_fill_i32(b.st.eos_step, -1, B, s);
+    launch_fill_i32(b.st.max_steps, 0x7fffffff, B, s);
+    launch_fill_i32(b.st.frames_after_eos, 0, B, s);
+    launch_fill_i32(b.st.broke, 0, B, s);
+    launch_fill_i32(b.st.n_active, B, 1, s);
+    std::vector<float> thr((size_t)B, INFINITY);
+    h2d(b.st.eos_threshold, thr.data(), thr.size() * sizeof(float), s);
+    std::fill(b.kv_len_host.begin(), b.kv_len_host.end(), 0);
+    b.has_noise = false;
+}
+
+void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64_t* steps, const int64_t* offsets) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    if (slot < 0 || slot >= b.B) throw Error(PTTS_EINVAL, "ptts-hip: voice state slot out of range");
+    for (int l = 0; l < d.n_layers; l++) {  // flow_transformer.go:538-549
+        if (!caches[l]) throw Error(PTTS_EINVAL, strfmt("native: voice model state module \"transformer.layers.%d.self_attn\" missing cache", l));
+        if (offsets[l] < 0) throw Error(PTTS_EINVAL, strfmt("native: voice model state module \"transformer.layers.%d.self_attn\" has negative offset %lld", l, (long long)offsets[l]));
+        if (offsets[l] > steps[l]) throw Error(PTTS_EINVAL, strfmt("native: voice model state module \"transformer.layers.%d.self_attn\" offset %lld exceeds cache length %lld", l, (long long)offsets[l], (long long)steps[l]));
+        if (offsets[l] != offsets[0]) throw Error(PTTS_EINVAL, "ptts-hip: per-layer voice offsets differ; one offset per utterance is supported");
+        if (offsets[l] > b.cap) throw Error(PTTS_EINVAL, "ptts-hip: voice state longer than the KV capacity");
+    }
+    for (int l = 0; l < d.n_layers; l++) {
+        size_t n = (size_t)2 * steps[l] * d.heads * d.hd;
+        DevBuf& raw = m.work(1, n * sizeof(float));
+        h2d(raw.p, caches[l], n * sizeof(float), m.stream);
+        launch_voice_scatter(raw.as<float>(), (int)steps[l], d.heads, d.hd, (int)offsets[l], slot, b.kc(l), b.vc(l),
+                             m.opts.kv == PTTS_KV_BF16, b.cap, m.stream);
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+    }
+    b.kv_len_host[slot] = (int32_t)offsets[0];
+    h2d(b.st.kv_len + slot, &b.kv_len_host[slot], sizeof(int32_t), m.stream);
+}
+
+// FlowLM.PromptText -> flowTransformer.prefill (flow_lm.go:155-187, flow_transformer.go:749-771), all slots at once,
+// ragged prompts packed as rows.  The hidden output is discarded by the reference, so the last layer stops after
+// its keys/values are in the cache.
+void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    hipStream_t s = m.stream;
+    const int B = b.B, D = d.d_model;
+    const int64_t R64 = row_offsets[B];
+    if (R64 == 0) return;
+    if (R64 < 0 || R64 > (1 << 24)) throw Error(PTTS_EINVAL, "ptts-hip: prompt row count out of range");
+    const int R = (int)R64;
+    std::vector<int32_t> row_slot((size_t)R), row_pos((size_t)R);
+    int max_pos = 0;
+    for (int sl = 0; sl < B; sl++) {
+        int64_t t = row_offsets[sl + 1] - row_offsets[sl];
+        if (t < 0) throw Error(PTTS_EINVAL, "ptts-hip: prompt row offsets must be non-decreasing");
+        if (b.kv_len_host[sl] + t > b.cap) throw Error(PTTS_EINVAL, strfmt("ptts-hip: prompt of %lld rows does not fit KV capacity %d (offset %d)", (long long)t, b.cap, b.kv_len_host[sl]));
+        for (int64_t i = 0; i < t; i++) {
+            int r = (int)(row_offsets[sl] + i);
+            row_slot[r] = sl;
+            row_pos[r] = b.kv_len_host[sl] + (int)i;
+            max_pos = std::max(max_pos, row_pos[r]);
+        }
+    }
+    const size_t f = sizeof(float);
+    DevBuf& idx = m.work(2, (size_t)2 * R * sizeof(int32_t));
+    int32_t* d_slot = idx.as<int32_t>();
+    int32_t* d_pos = d_slot + R;
+    h2d(d_slot, row_slot.data(), (size_t)R * sizeof(int32_t), s);
+    h2d(d_pos, row_pos.data(), (size_t)R * sizeof(int32_t), s);
+    DevBuf& wsb = m.work(3, ((size_t)R * (size_t)(D + D + 3 * D + D + d.ffn)) * f);
+    float* px = wsb.as<float>();
+    float* pxn = px + (size_t)R * D;
+    float* pqkv = pxn + (size_t)R * D;
+    float* pattn = pqkv + (size_t)R * 3 * D;
+    float* pff = pattn + (size_t)R * D;
+    PTTS_HIP(hipMemcpyAsync(px, rows_dev, (size_t)R * D * f, hipMemcpyDeviceToDevice, s));
+    const bool kvb = m.opts.kv == PTTS_KV_BF16;
+    for (int l = 0; l < d.n_layers; l++) {
+        const auto& L = d.layers[l];
+        launch_layernorm(mkln(m, px, flat(D), L.n1, pxn, D, R), s);
+        launch_gemm(mk(m, pxn, flat(D), L.in_proj, pqkv, flat(3 * D), R), s);
+        launch_rope_rows(pqkv, 3 * D, 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_rope_rows(pqkv, 3 * D, D, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_kv_append(pqkv, 3 * D, D, d.heads, d.hd, d_slot, d_pos, R, b.kc(l), b.vc(l), kvb, b.cap, s);
+        if (l == d.n_layers - 1) break;
+        AttnArgs a;
+        a.q = pqkv; a.q_ld = 3 * D; a.q_col0 = 0;
+        a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
+        a.k_seg_stride = (int64_t)d.heads * b.cap * d.hd; a.k_head_stride = (int64_t)b.cap * d.hd; a.k_row_stride = d.hd;
+        a.row_seg = d_slot; a.row_pos = d_pos;
+        a.context = -1;
+        a.out = pattn; a.out_ld = D;
+        a.rows = R; a.heads = d.heads; a.max_keys = max_pos + 1;
+        launch_attention(a, s);
+        GemmArgs go = mk(m, pattn, flat(D), L.out_proj, px, flat(D), R);
+        go.R = px; go.epi = EPI_RESADD;
+        launch_gemm(go, s);
+        launch_layernorm(mkln(m, px, flat(D), L.n2, pxn, D, R), s);
+        GemmArgs g1 = mk(m, pxn, flat(D), L.l1, pff, flat(d.ffn), R);
+        g1.epi = EPI_GELU;
+        launch_gemm(g1, s);
+        GemmArgs g2 = mk(m, pff, flat(d.ffn), L.l2, px, flat(D), R);
+        g2.R = px; g2.epi = EPI_RESADD;
+        launch_gemm(g2, s);
+    }
+    for (int sl = 0; sl < B; sl++) b.kv_len_host[sl] += (int32_t)(row_offsets[sl + 1] - row_offsets[sl]);
+    h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)B * sizeof(int32_t), s);
+}
+
+// FlowLM.SampleNextLatentStateful minus the host glue (flow_lm.go:252-288): input_linear, 6 x forwardWithState(Tq=1),
+// out_norm, out_eos, LSD decode through the flow net.  Everything reads device state, so the sequence is graph-capturable.
+void step_core(Batch& b, int lsd) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    hipStream_t s = m.stream;
+    const int B = b.B, D = d.d_model, C = d.flow_dim, NA = d.ada_all.out;
+    const bool kvb = m.opts.kv == PTTS_KV_BF16;
+    float* x = b.x.as<float>();
+    float* xn = b.xn.as<float>();
+    float* qkv = b.qkv.as<float>();
+    float* attn = b.attn.as<float>();
+    float* ff = b.ff.as<float>();
+    launch_gemm(mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B), s);
+    for (int l = 0; l < d.n_layers; l++) {
+        const auto& L = d.layers[l];
+        launch_layernorm(mkln(m, x, flat(D), L.n1, xn, D, B), s);
+        launch_gemm(mk(m, xn, flat(D), L.in_proj, qkv, flat(3 * D), B), s);
+        AttnArgs a;
+        a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
+        a.k_seg_stride = (int64_t)d.heads * b.cap * d.hd; a.k_head_stride = (int64_t)b.cap * d.hd; a.k_row_stride = d.hd;
+        a.seg_len = b.st.kv_len; a.active = b.st.active;
+        a.context = -1;
+        a.out = attn; a.out_ld = D;
+        a.rows = B; a.heads = d.heads; a.max_keys = b.cap;
+        a.fused_step = 1; a.qkv = qkv; a.qkv_ld = 3 * D; a.d_model = D;
+        a.cos_t = m.at<float>(d.rope_cos); a.sin_t = m.at<float>(d.rope_sin); a.cap = b.cap;
+        launch_attention(a, s);
+        GemmArgs go = mk(m, attn, flat(D), L.out_proj, x, flat(D), B);
+        go.R = x; go.epi = EPI_RESADD;
+        launch_gemm(go, s);
+        launch_layernorm(mkln(m, x, flat(D), L.n2, xn, D, B), s);
+        GemmArgs g1 = mk(m, xn, flat(D), L.l1, ff, flat(d.ffn), B);
+        g1.epi = EPI_GELU;
+        launch_gemm(g1, s);
+        GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
+        g2.R = x; g2.epi = EPI_RESADD;
+        launch_gemm(g2, s);
+    }
+    float* last = b.last.as<float>();
+    launch_layernorm(mkln(m, x, flat(D), d.out_norm, last, D, B), s);
+    launch_gemm(mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B), s);
+    // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
+    const float* tc = m.tcomb.at(lsd)->as<float>();
+    float* sy = b.sy.as<float>();
+    float* ada = b.ada.as<float>();
+    float* fx = b.fx.as<float>();
+    float* fh = b.fh.as<float>();
+    float* fh2 = b.fh2.as<float>();
+    float* cur = b.cur.as<float>();
+    for (int i = 0; i < lsd; i++) {
+        GemmArgs gc = mk(m, last, flat(D), d.cond_embed, sy, flat(C), B);  // sy = silu(0.5*(e_s+e_t) + cond_embed(c))
+        gc.epi = EPI_SILU; gc.addvec = tc + (size_t)i * C;
+        launch_gemm(gc, s);
+        launch_gemm(mk(m, sy, flat(C), d.ada_all, ada, flat(NA), B), s);
+        launch_gemm(mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B), s);
+        for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
+            const auto& rb = d.rb[r];
+            LnArgs ln = mkln(m, fx, flat(C), rb.ln, fh, C, B);
+            ln.shift = ada + (size_t)r * 3 * C; ln.scale = ln.shift + C; ln.ldmod = NA;
+            launch_layernorm(ln, s);
+            GemmArgs g0 = mk(m, fh, flat(C), rb.mlp0, fh2, flat(C), B);
+            g0.epi = EPI_SILU;
+            launch_gemm(g0, s);
+            GemmArgs g2 = mk(m, fh2, flat(C), rb.mlp2, fx, flat(C), B);
+            g2.R = fx; g2.epi = EPI_GATE_RESADD; g2.gate = ada + (size_t)r * 3 * C + 2 * C; g2.ldg = NA;
+            launch_gemm(g2, s);
+        }
+        LnArgs lf;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
+        lf.x = fx; lf.xmap = flat(C); lf.eps = 1e-6f; lf.y = fh; lf.ldy = C; lf.rows = B; lf.d = C;
+        lf.shift = ada + (size_t)d.flow_depth * 3 * C; lf.scale = lf.shift + C; lf.ldmod = NA;
+        launch_layernorm(lf, s);
+        GemmArgs gf = mk(m, fh, flat(C), d.final_linear, cur, flat(d.ldim), B);  // current += flow * (1/steps)
+        gf.R = cur; gf.epi = EPI_AXPY; gf.alpha = 1.0f / (float)lsd;
+        launch_gemm(gf, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mimi: Model.LatentToMimi + MimiModel.DecodeFromLatent (model.go:141-319, mimi.go:719-789)
+// ------------------------------------------------------------------------------------------------
+static void mimi_decode_group(Model& m, const float* lat, int64_t lat_bstride, int B, int T, float* pcm, float* mimi_latent) {
+    const Desc& d = m.d;
+    hipStream_t s = m.stream;
+    const int C = d.mimi_dim, S = d.up_stride, T1 = T * S, F = d.mimi_ffn;
+    const int P0 = d.init_k - 1;
+    const size_t f = sizeof(float);
+    // stage lengths / pads
+    int Ls[4], Ps[4];  // channels-last buffers c0, u1, u2, u3: length and history rows
+    Ls[0] = T1; Ps[0] = 1;
+    for (int j = 0; j < 3; j++) {
+        Ls[j + 1] = Ls[j] * d.strides[j];
+        int need_next = j < 2 ? 1 : d.final_k - 1;
+        Ps[j + 1] = std::max(d.rb_k1[j] - 1, need_next);
+    }
+    size_t n_xp = (size_t)B * (1 + T) * C;
+    size_t n_up = (size_t)B * (P0 + T1) * C;
+    size_t n_n1 = (size_t)B * T1 * C, n_qkv = (size_t)B * T1 * 3 * C, n_ff = (size_t)B * T1 * F;
+    size_t n_c[4], n_h[3];
+    for (int j = 0; j < 4; j++) n_c[j] = (size_t)B * (Ps[j] + Ls[j]) * d.sea_ch[j];
+    for (int j = 0; j < 3; j++) n_h[j] = (size_t)B * ((d.rb_k2[j] - 1) + Ls[j + 1]) * d.sea_hidden[j];
+    size_t total = n_xp + n_up + n_n1 + n_qkv + n_n1 + n_ff + n_c[0] + n_c[1] + n_c[2] + n_c[3] + std::max(n_h[0], std::max(n_h[1], n_h[2]));
+    DevBuf& wsb = m.work(4, total * f);
+    float* xp = wsb.as<float>();
+    float* up = xp + n_xp;
+    float* n1 = up + n_up;
+    float* qkv = n1 + n_n1;
+    float* attn = qkv + n_qkv;
+    float* ffb = attn + n_n1;
+    float* cb[4];
+    cb[0] = ffb + n_ff;
+    for (int j = 1; j < 4; j++) cb[j] = cb[j - 1] + n_c[j - 1];
+    float* hb = cb[3] + n_c[3];
+
+    launch_projector(lat, lat_bstride, m.at<float>(d.proj_w), m.at<float>(d.proj_b), B, T, d.ldim, C, xp, s);
+    if (mimi_latent) launch_btc_to_bct(xp, 1, B, C, T, mimi_latent, s);
+    launch_zero_rows(up, (int64_t)(P0 + T1) * C, B, (int64_t)P0 * C, s);
+    launch_upsample_depthwise(xp, m.at<float>(d.up_w0), m.at<float>(d.up_w1), nullptr, B, T, C, S, up, P0, s);
+    // decoder transformer (mimi.go:245-441, 506-525): positions restart at 0 for every utterance, window `context`
+    const RowMap upm = seg(C, T1, (int64_t)(P0 + T1) * C);
+    float* upx = up + (size_t)P0 * C;
+    const int R = B * T1;
+    for (int l = 0; l < d.mimi_layers; l++) {
+        const auto& L = d.ml[l];
+        launch_layernorm(mkln(m, upx, upm, L.n1, n1, C, R), s);
+        launch_gemm(mk(m, n1, flat(C), L.in_proj, qkv, flat(3 * C), R), s);
+        launch_rope_rows(qkv, 3 * C, 0, d.mimi_heads, d.mimi_hd, nullptr, 0, T1, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_rope_rows(qkv, 3 * C, C, d.mimi_heads, d.mimi_hd, nullptr, 0, T1, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        AttnArgs a;
+        a.q = qkv; a.q_ld = 3 * C; a.q_col0 = 0;
+        a.k = qkv + C; a.v = qkv + 2 * C; a.kv_bf16 = 0;
+        a.k_seg_stride = (int64_t)T1 * 3 * C; a.k_head_stride = d.mimi_hd; a.k_row_stride = 3 * C;
+        a.rows_per_seg = T1;
+        a.context = d.mimi_ctx;
+        a.out = attn; a.out_ld = C;
+        a.rows = R; a.heads = d.mimi_heads; a.max_keys = std::min(T1, d.mimi_ctx);
+        launch_attention(a, s);
+        GemmArgs go = mk(m, attn, flat(C), L.out_proj, upx, upm, R);
+        go.R = upx; go.epi = L.ls1 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; go.scale = m.at<float>(L.ls1);
+        launch_gemm(go, s);
+        launch_layernorm(mkln(m, upx, upm, L.n2, n1, C, R), s);
+        GemmArgs g1 = mk(m, n1, flat(C), L.l1, ffb, flat(F), R);
+        g1.epi = EPI_GELU;
+        launch_gemm(g1, s);
+        GemmArgs g2 = mk(m, ffb, flat(F), L.l2, upx, upm, R);
+        g2.R = upx; g2.epi = L.ls2 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; g2.scale = m.at<float>(L.ls2);
+        launch_gemm(g2, s);
+    }
+    // SEANet decoder (mimi.go:740-788): causal convs as GEMMs over contiguous channels-last windows
+    {
+        const int ch = d.sea_ch[0];
+        launch_zero_rows(cb[0], (int64_t)(Ps[0] + Ls[0]) * ch, B, (int64_t)Ps[0] * ch, s);
+        GemmArgs g = mk(m, up, seg(C, T1, (int64_t)(P0 + T1) * C), d.init_conv, cb[0] + (size_t)Ps[0] * ch,
+                        seg(ch, Ls[0], (int64_t)(Ps[0] + Ls[0]) * ch), R);
+        g.epi = EPI_ELU;  // x = elu(initConv(x))
+        launch_gemm(g, s);
+    }
+    for (int j = 0; j < 3; j++) {
+        const int cin = d.sea_ch[j], cout = d.sea_ch[j + 1], st = d.strides[j], hid = d.sea_hidden[j];
+        const int Lin_ = Ls[j], Lout = Ls[j + 1], Pin = Ps[j], Pout = Ps[j + 1], Ph = d.rb_k2[j] - 1;
+        float* in = cb[j];
+        float* u = cb[j + 1];
+        launch_zero_rows(u, (int64_t)(Pout + Lout) * cout, B, (int64_t)Pout * cout, s);
+        // transposed conv: window [x[t-1], x[t]] starts one row before t
+        GemmArgs gu = mk(m, in + (size_t)(Pin - 1) * cin, seg(cin, Lin_, (int64_t)(Pin + Lin_) * cin), d.up[j],
+                         u + (size_t)Pout * cout, seg((int64_t)st * cout, Lin_, (int64_t)(Pout + Lout) * cout), B * Lin_);
+        gu.aop = j == 0 ? AOP_NONE : AOP_ELU;  // elu(x) precedes up2/up3; c0 was activated in the initConv epilogue
+        launch_gemm(gu, s);
+        // residual block: x + conv_k1(elu(conv_k3(elu(x))))  (mimi.go:146-164)
+        if (Ph > 0) launch_zero_rows(hb, (int64_t)(Ph + Lout) * hid, B, (int64_t)Ph * hid, s);
+        GemmArgs g1 = mk(m, u + (size_t)(Pout - (d.rb_k1[j] - 1)) * cout, seg(cout, Lout, (int64_t)(Pout + Lout) * cout), d.rb1[j],
+                         hb + (size_t)Ph * hid, seg(hid, Lout, (int64_t)(Ph + Lout) * hid), B * Lout);
+        g1.aop = AOP_ELU; g1.epi = EPI_ELU;
+        launch_gemm(g1, s);
+        GemmArgs g2 = mk(m, hb, seg(hid, Lout, (int64_t)(Ph + Lout) * hid), d.rb2[j], u + (size_t)Pout * cout,
+                         seg(cout, Lout, (int64_t)(Pout + Lout) * cout), B * Lout);
+        g2.R = u + (size_t)Pout * cout; g2.epi = EPI_RESADD;
+        launch_gemm(g2, s);
+    }
+    launch_conv_final(cb[3], Ps[3], m.at<float>(d.final_w), m.at<float>(d.final_b), B, Ls[3], d.sea_ch[3], d.final_k, pcm, s);
+}
+
+void mimi_decode(Model& m, const float* lat, int64_t lat_bstride, int B, int T, float* pcm, float* mimi_latent) {
+    if (B <= 0 || T <= 0) return;
+    if ((int64_t)T * m.d.up_stride > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)T * m.d.up_stride));
+    // bound the workspace: ~1.7 MB of f32 activations per latent frame at the reference shapes
+    const Desc& d = m.d;
+    double per_frame = 4.0 * ((double)d.up_stride * (d.mimi_dim * 6.0 + d.mimi_ffn) +
+                              (double)d.samples_per_frame * (d.sea_ch[3] * 1.6 + d.sea_ch[2] * 0.5 + d.sea_ch[1] * 0.2));
+    int group = (int)std::max(1.0, std::min((double)B, 24e9 / (per_frame * T)));
+    const int64_t spu = (int64_t)T * d.samples_per_frame;
+    for (int b0 = 0; b0 < B; b0 += group) {
+        int nb = std::min(group, B - b0);
+        mimi_decode_group(m, lat + (int64_t)b0 * lat_bstride, lat_bstride, nb, T, pcm + (int64_t)b0 * spu,
+                          mimi_latent ? mimi_latent + (int64_t)b0 * d.mimi_dim * T : nullptr);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// GenerateAudio for a batch of independent utterance chunks
+// ------------------------------------------------------------------------------------------------
+static int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go:61-67, text/prepare.go:38-48
+    int ms = r.max_steps;
+    if (ms <= 0) ms = r.estimated_max_steps;
+    if (ms <= 0) ms = (int)std::ceil(((double)r.n_tokens / 3.0 + 2.0) * 12.5);
+    return ms;
+}
+
+static void capture_step_graph(Batch& b, int lsd) {
+    Model& m = *b.m;
+    if (b.graph && b.graph_lsd == lsd && b.graph_noise == b.has_noise) return;
+    if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    hipGraph_t g = nullptr;
+    PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
+    const int ld = m.d.ldim;
+    const int64_t ls = (int64_t)b.max_steps * ld;
+    launch_step_input(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), ld, b.B, b.in32.as<float>(), m.stream);
+    launch_step_noise(b.st, b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B, b.cur.as<float>(), m.stream);
+    step_core(b, lsd);
+    launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    PTTS_HIP(hipStreamEndCapture(m.stream, &g));
+    hipError_t e = hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (e != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipGraphInstantiate failed: %s", hipGetErrorString(e)));
+    b.graph_lsd = lsd;
+    b.graph_noise = b.has_noise;
+}
+
+static void enqueue_step(Batch& b, int lsd, bool use_graph) {
+    Model& m = *b.m;
+    if (use_graph) {
+        PTTS_HIP(hipGraphLaunch(b.graph, m.stream));
+        return;
+    }
+    const int ld = m.d.ldim;
+    const int64_t ls = (int64_t)b.max_steps * ld;
+    launch_step_input(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), ld, b.B, b.in32.as<float>(), m.stream);
+    launch_step_noise(b.st, b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B, b.cur.as<float>(), m.stream);
+    step_core(b, lsd);
+    launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+}
+
+static void fail_req(ptts_result& r, int code) {
+    r.status = code;
+}
+
+static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector<int>& idx, ptts_result* res, int lsd) {
+    const Desc& d = m.d;
+    hipStream_t s = m.stream;
+    const int B = (int)idx.size(), D = d.d_model, ld = d.ldim;
+    std::vector<int> ms((size_t)B), tp((size_t)B), off((size_t)B);
+    int cap_need = 0, ms_max = 0;
+    for (int i = 0; i < B; i++) {
+        const ptts_request& r = reqs[idx[i]];
+        ms[i] = resolve_max_steps(r);
+        tp[i] = (int)r.n_tokens + (r.voice_embedding ? (int)r.voice_frames : 0);
+        off[i] = r.voice_caches ? (int)r.voice_offsets[0] : 0;
+        cap_need = std::max(cap_need, off[i] + tp[i] + ms[i]);
+        ms_max = std::max(ms_max, ms[i]);
+    }
+    int cap = (cap_need + 63) / 64 * 64;
+    if (cap > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=%d seq=1", cap_need));
+    if (!m.cached_batch || m.cached_batch->B != B || m.cached_batch->cap < cap || m.cached_batch->max_steps < ms_max) {
+        m.cached_batch.reset();
+        m.cached_batch.reset(batch_new(m, B, cap, ms_max));
+    }
+    Batch& b = *m.cached_batch;
+    batch_reset(b);
+    {
+        std::vector<int32_t> v_ms(ms.begin(), ms.end()), v_fae((size_t)B);
+        std::vector<float> v_thr((size_t)B);
+        for (int i = 0; i < B; i++) { v_fae[i] = reqs[idx[i]].frames_after_eos; v_thr[i] = reqs[idx[i]].eos_threshold; }
+        h2d(b.st.max_steps, v_ms.data(), (size_t)B * 4, s);
+        h2d(b.st.frames_after_eos, v_fae.data(), (size_t)B * 4, s);
+        h2d(b.st.eos_threshold, v_thr.data(), (size_t)B * 4, s);
+    }
+    for (int i = 0; i < B; i++) {
+        const ptts_request& r = reqs[idx[i]];
+        if (r.voice_caches) batch_set_voice(b, i, r.voice_caches, r.voice_cache_steps, r.voice_offsets);
+    }
+    // text (+ voice) embeddings packed as rows (runtime_native_safetensors.go:89-119)
+    std::vector<int64_t> row_off((size_t)B + 1, 0);
+    for (int i = 0; i < B; i++) row_off[i + 1] = row_off[i] + tp[i];
+    const int64_t R = row_off[B];
+    DevBuf& rows = m.work(5, (size_t)R * D * sizeof(float));
+    {
+        std::vector<int64_t> ids;
+        for (int i = 0; i < B; i++) ids.insert(ids.end(), reqs[idx[i]].tokens, reqs[idx[i]].tokens + reqs[idx[i]].n_tokens);
+        DevBuf& dids = m.work(6, ids.size() * sizeof(int64_t));
+        h2d(dids.p, ids.data(), ids.size() * sizeof(int64_t), s);
+        int64_t id0 = 0;
+        for (int i = 0; i < B; i++) {
+            const ptts_request& r = reqs[idx[i]];
+            float* dst = rows.as<float>() + row_off[i] * D;
+            int64_t tv = r.voice_embedding ? r.voice_frames : 0;
+            if (tv) h2d(dst, r.voice_embedding, (size_t)tv * D * sizeof(float), s);
+            launch_embed_gather(m.at<float>(d.embed), dids.as<int64_t>() + id0, (int)r.n_tokens, D, dst + tv * D, s);
+            id0 += r.n_tokens;
+        }
+    }
+    batch_prompt(b, rows.as<float>(), row_off.data());
+    // injected sampling noise (flow_lm.go:283-288)
+    bool any_noise = false;
+    for (int i = 0; i < B; i++) any_noise |= reqs[idx[i]].noise != nullptr;
+    b.has_noise = any_noise;
+    if (any_noise) {
+        size_t n = (size_t)B * b.max_steps * ld;
+        b.noise.ensure(n * sizeof(float));
+        PTTS_HIP(hipMemsetAsync(b.noise.p, 0, n * sizeof(float), s));
+        for (int i = 0; i < B; i++)
+            if (reqs[idx[i]].noise) h2d(b.noise.as<float>() + (size_t)i * b.max_steps * ld, reqs[idx[i]].noise, (size_t)ms[i] * ld * sizeof(float), s);
+    }
+    m.tcomb_for(lsd);
+    const bool use_graph = m.opts.use_graph != 0;
+    if (use_graph) capture_step_graph(b, lsd);
+    bool may_stop = false, any_cb = false;
+    for (int i = 0; i < B; i++) {
+        may_stop |= reqs[idx[i]].eos_threshold < 1e30f;
+        any_cb |= reqs[idx[i]].step_callback != nullptr;
+    }
+    std::vector<char> cancelled((size_t)B, 0);
+    std::vector<int32_t> act((size_t)B, 1);
+    for (int step = 0; step < ms_max; step++) {
+        int n_cancel = 0;
+        for (int i = 0; i < B; i++) {  // ctx.Err() check before every step (:156-159)
+            const ptts_request& r = reqs[idx[i]];
+            if (r.cancel && *r.cancel) cancelled[i] = 1;
+            n_cancel += cancelled[i];
+        }
+        if (n_cancel == B) break;
+        enqueue_step(b, lsd, use_graph);
+        if (any_cb) {  // StepCallback runs synchronously after the step (:194-196)
+            std::vector<int32_t> before = act, broke((size_t)B);
+            d2h(act.data(), b.st.active, (size_t)B * 4, s);
+            d2h(broke.data(), b.st.broke, (size_t)B * 4, s);
+            for (int i = 0; i < B; i++) {  // not called for the iteration that leaves through `break` (:185-187)
+                const ptts_request& r = reqs[idx[i]];
+                if (r.step_callback && before[i] && !broke[i] && !cancelled[i]) r.step_callback(r.callback_user, step + 1, ms[i]);
+            }
+            bool any = false;
+            for (int i = 0; i < B; i++) any |= act[i] != 0;
+            if (!any) break;
+        } else if (may_stop && (step % 8) == 7) {
+            PTTS_HIP(hipMemcpyAsync(b.n_active_pinned, b.st.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            PTTS_HIP(hipStreamSynchronize(s));
+            if (*b.n_active_pinned <= 0) break;
+        }
+    }
+    std::vector<int32_t> nf((size_t)B), es((size_t)B);
+    d2h(nf.data(), b.st.n_frames, (size_t)B * 4, s);
+    d2h(es.data(), b.st.eos_step, (size_t)B * 4, s);
+    int T = 0;
+    for (int i = 0; i < B; i++) if (!cancelled[i]) T = std::max(T, nf[i]);
+    const int64_t spf = d.samples_per_frame;
+    if (T > 0) {
+        DevBuf& pcm = m.work(7, (size_t)B * T * spf * sizeof(float));
+        // all decoder ops are causal, so decoding every utterance to the longest length and truncating is exact
+        mimi_decode(m, b.latents.as<float>(), (int64_t)b.max_steps * ld, B, T, pcm.as<float>(), nullptr);
+        PTTS_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < B; i++) {
+            ptts_result& r = res[idx[i]];
+            if (cancelled[i]) { fail_req(r, PTTS_ECANCELLED); continue; }
+            r.n_frames = nf[i];
+            r.eos_step = es[i];
+            r.n_samples = (int64_t)nf[i] * spf;
+            r.pcm = (float*)malloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
+            if (!r.pcm) { fail_req(r, PTTS_ENOMEM); continue; }
+            d2h(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), s);
+            if (reqs[idx[i]].want_latents) {
+                r.latents = (float*)malloc((size_t)std::max(1, nf[i]) * ld * sizeof(float));
+                if (!r.latents) { fail_req(r, PTTS_ENOMEM); continue; }
+                d2h(r.latents, b.latents.as<float>() + (size_t)i * b.max_steps * ld, (size_t)nf[i] * ld * sizeof(float), s);
+            }
+            r.status = PTTS_OK;
+        }
+    } else {
+        for (int i = 0; i < B; i++) fail_req(res[idx[i]], PTTS_ECANCELLED);
+    }
+}
+
+void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res) {
+    std::lock_guard<std::mutex> lock(m.mu);
+    m.use_device();
+    const Desc& d = m.d;
+    std::map<int, std::vector<int>> groups;  // lsd_steps -> request indices
+    std::string first_err;
+    for (int i = 0; i < n; i++) {
+        ptts_result& r = res[i];
+        std::memset(&r, 0, sizeof r);
+        r.eos_step = -1;
+        const ptts_request& q = reqs[i];
+        std::string err;
+        if (!q.tokens || q.n_tokens <= 0) err = "generate: token slice must not be empty";
+        else if (q.voice_embedding && q.voice_caches) err = "generate: voice embedding and voice model state are mutually exclusive";
+        else if (q.voice_caches && (!q.voice_cache_steps || !q.voice_offsets)) err = "generate: load voice model state: missing cache steps/offsets";
+        else {
+            for (int64_t t = 0; t < q.n_tokens; t++)
+                if (q.tokens[t] < 0 || q.tokens[t] >= d.n_bins) {
+                    err = strfmt("generate: text embeddings: native: token id %lld (%lld) out of range [0,%d)", (long long)t, (long long)q.tokens[t], d.n_bins);
+                    break;
+                }
+        }
+        if (!err.empty()) {
+            r.status = PTTS_EINVAL;
+            if (first_err.empty()) first_err = err;
+            continue;
+        }
+        groups[q.lsd_steps <= 0 ? 1 : q.lsd_steps].push_back(i);
+    }
+    const int mb = std::max(1, m.opts.max_batch);
+    for (auto& kv : groups) {
+        const std::vector<int>& all = kv.second;
+        for (size_t o = 0; o < all.size(); o += (size_t)mb) {
+            std::vector<int> idx(all.begin() + (long)o, all.begin() + (long)std::min(all.size(), o + (size_t)mb));
+            try {
+                generate_chunk(m, reqs, idx, res, kv.first);
+            } catch (const Error& e) {
+                for (int i : idx) { ptts_free_result(&res[i]); res[i].status = e.code; res[i].eos_step = -1; }
+                if (first_err.empty()) first_err = e.what();
+            }
+        }
+    }
+    if (!first_err.empty()) set_last_error(first_err);
+}
+
+}  // namespace ptts

@@ -1,0 +1,96 @@
+// runtime.h -- host-side engine above the kernels: device model, batch of FlowLM states,
+// prefill, AR step (hipGraph), Mimi decode, GenerateAudio loop.
+#pragma once
+
+#include "kernels.h"
+#include "model.h"
+
+namespace ptts {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    void ensure(size_t bytes) {  // grow-only
+        if (bytes <= n && p) return;
+        release();
+        if (bytes == 0) bytes = 256;
+        PTTS_HIP(hipMalloc(&p, bytes));
+        n = bytes;
+    }
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+struct Batch;
+
+struct Model {
+    Desc d;
+    ptts_opts opts;
+    uint8_t* arena = nullptr;
+    bool own_arena = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::map<int, std::unique_ptr<DevBuf>> tcomb;  // lsd_steps -> [n][flow_dim]: 0.5*(embed_s(i/n) + embed_t((i+1)/n))
+    std::vector<std::unique_ptr<DevBuf>> ws;       // grow-only workspaces (Mimi decode, prefill)
+    std::unique_ptr<Batch> cached_batch;
+
+    ~Model();
+    template <class T> const T* at(size_t off) const { return off == NONE ? nullptr : reinterpret_cast<const T*>(arena + off); }
+    DevBuf& work(size_t i, size_t bytes) {
+        while (ws.size() <= i) ws.emplace_back(new DevBuf());
+        ws[i]->ensure(bytes);
+        return *ws[i];
+    }
+    void use_device() const { PTTS_HIP(hipSetDevice(device)); }
+    const float* tcomb_for(int lsd_steps);
+    void compute_tcomb(float s, float t, float* dst /* device [flow_dim] */);
+};
+
+// n_slots independent FlowLMState (flow_lm.go:45-49) in HBM + the per-step workspace
+struct Batch {
+    Model* m = nullptr;
+    int B = 0;
+    int cap = 0;             // KV capacity per slot (keys)
+    int max_steps = 0;       // rows of `latents` per slot
+    DevBuf kcache, vcache;   // [L][B][H][cap][hd]
+    DevBuf state_i32;        // StepState arrays
+    DevBuf state_f32;
+    StepState st{};
+    std::vector<int32_t> kv_len_host;
+    // step workspace
+    DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step;
+    DevBuf latents;          // [B][max_steps][ldim]
+    DevBuf noise;            // [B][max_steps][ldim] or empty
+    bool has_noise = false;
+    hipGraphExec_t graph = nullptr;
+    int graph_lsd = 0;
+    bool graph_noise = false;
+    int32_t* n_active_pinned = nullptr;
+
+    ~Batch();
+    size_t kv_elem() const { return m->opts.kv == PTTS_KV_BF16 ? 2 : 4; }
+    void* kc(int layer) const { return (char*)kcache.p + (size_t)layer * B * m->d.heads * cap * m->d.hd * kv_elem(); }
+    void* vc(int layer) const { return (char*)vcache.p + (size_t)layer * B * m->d.heads * cap * m->d.hd * kv_elem(); }
+};
+
+Model* model_open(Plan* plan, void* device_arena, int fill);
+Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);
+void batch_reset(Batch& b);
+void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64_t* steps, const int64_t* offsets);
+// rows: device [R, d_model]; row_offsets host [B+1]
+void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
+// core of one AR step on device state: in32 [B, ldim], cur [B, ldim] (= x0) -> cur (= frame), eos, last; appends KV at kv_len
+void step_core(Batch& b, int lsd_steps);
+void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev);
+void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
+
+}  // namespace ptts

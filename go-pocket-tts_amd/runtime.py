@@ -1,0 +1,512 @@
+"""Host-side mirror of the reference's Runtime seam over the C ABI (include/ptts.h).
+
+Reference: `tts.Runtime` (internal/tts/runtime.go:42-45), `RuntimeGenerateConfig` (:17-31),
+`VoiceEmbedding` (:11-14), `nativeSafetensorsRuntime` (runtime_native_safetensors.go:20-244).
+The reference toolchain (Go) is absent from the build image, so this ctypes layer plays the
+role the cgo shim in INTEGRATION.md plays for the Go service: same method names, argument
+meaning and error behaviour.  There is no CPU fallback: if libptts_hip.so is missing or no
+HIP device is visible, every call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from dataclasses import dataclass, field
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libptts_hip.so")
+
+PTTS_OK, PTTS_EINVAL, PTTS_EIO, PTTS_EFORMAT, PTTS_ENODEVICE, PTTS_ECANCELLED, PTTS_ENOMEM = range(7)
+WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
+KV_F32, KV_BF16 = 0, 1
+
+_FP = C.POINTER(C.c_float)
+_IP = C.POINTER(C.c_int64)
+_STEP_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)
+
+
+class PttsError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(msg)
+        self.code = code
+
+
+class Cancelled(PttsError):
+    """ctx.Err() of the reference (runtime_native_safetensors.go:156-159)."""
+
+
+class _Opts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("weights", C.c_int32), ("kv", C.c_int32), ("max_batch", C.c_int32),
+                ("use_graph", C.c_int32), ("reserved", C.c_int32 * 11)]
+
+
+class _Info(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in ("d_model", "n_heads", "n_layers", "ffn", "ldim", "n_bins", "flow_dim", "flow_depth",
+                                         "mimi_dim", "mimi_heads", "mimi_layers", "mimi_context", "sample_rate",
+                                         "samples_per_frame", "steps_per_latent")] + \
+               [("frame_rate", C.c_double), ("encoder_frame_rate", C.c_double), ("n_params", C.c_int64),
+                ("arena_bytes", C.c_int64), ("weights", C.c_int32), ("kv", C.c_int32)]
+
+
+class _Request(C.Structure):
+    _fields_ = [("tokens", _IP), ("n_tokens", C.c_int64), ("temperature", C.c_float), ("eos_threshold", C.c_float),
+                ("max_steps", C.c_int32), ("estimated_max_steps", C.c_int32), ("lsd_steps", C.c_int32),
+                ("frames_after_eos", C.c_int32), ("voice_embedding", _FP), ("voice_frames", C.c_int64),
+                ("voice_caches", C.POINTER(_FP)), ("voice_cache_steps", _IP), ("voice_offsets", _IP), ("noise", _FP),
+                ("step_callback", _STEP_CB), ("callback_user", C.c_void_p), ("cancel", C.POINTER(C.c_int32)),
+                ("want_latents", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("pcm", _FP), ("n_samples", C.c_int64), ("latents", _FP), ("n_frames", C.c_int32), ("eos_step", C.c_int32),
+                ("status", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+_lib = None
+
+# every symbol include/ptts.h declares (tests check that the built library exports all of them)
+ABI_SYMBOLS = [
+    "ptts_default_opts", "ptts_model_open", "ptts_model_open_bytes", "ptts_model_close", "ptts_model_info", "ptts_last_error",
+    "ptts_plan_create", "ptts_plan_create_bytes", "ptts_plan_arena_bytes", "ptts_model_open_planned", "ptts_plan_free",
+    "ptts_generate", "ptts_free_result", "ptts_text_embeddings", "ptts_batch_new", "ptts_batch_free", "ptts_batch_reset",
+    "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
+    "ptts_decode_latents", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
+    "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
+]
+
+
+def build(force: bool = False) -> str:
+    """Compiles the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    args = ["make", "-s", "-C", _HERE, "-j8"]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PttsError(PTTS_ENODEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        L = C.CDLL(LIB_PATH)
+        L.ptts_last_error.restype = C.c_char_p
+        L.ptts_version.restype = C.c_char_p
+        L.ptts_plan_arena_bytes.restype = C.c_size_t
+        L.ptts_plan_arena_bytes.argtypes = [C.c_void_p]
+        L.ptts_plan_free.argtypes = [C.c_void_p]
+        L.ptts_model_close.argtypes = [C.c_void_p]
+        L.ptts_batch_free.argtypes = [C.c_void_p]
+        L.ptts_model_open.argtypes = [C.c_char_p, C.POINTER(_Opts), C.POINTER(C.c_void_p)]
+        L.ptts_model_open_bytes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Opts), C.POINTER(C.c_void_p)]
+        L.ptts_plan_create.argtypes = [C.c_char_p, C.POINTER(_Opts), C.POINTER(C.c_void_p)]
+        L.ptts_plan_create_bytes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Opts), C.POINTER(C.c_void_p)]
+        L.ptts_model_open_planned.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ptts_model_info.argtypes = [C.c_void_p, C.POINTER(_Info)]
+        L.ptts_generate.argtypes = [C.c_void_p, C.POINTER(_Request), C.c_int32, C.POINTER(_Result)]
+        L.ptts_free_result.argtypes = [C.POINTER(_Result)]
+        L.ptts_text_embeddings.argtypes = [C.c_void_p, _IP, C.c_int64, _FP]
+        L.ptts_batch_new.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.ptts_batch_reset.argtypes = [C.c_void_p]
+        L.ptts_batch_set_voice_state.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_FP), _IP, _IP]
+        L.ptts_batch_prompt.argtypes = [C.c_void_p, _FP, _IP]
+        L.ptts_batch_step.argtypes = [C.c_void_p, _FP, C.c_int32, _FP, _FP, _FP, _FP]
+        L.ptts_batch_offsets.argtypes = [C.c_void_p, _IP]
+        L.ptts_batch_read_kv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, _FP]
+        L.ptts_decode_latents.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP]
+        L.ptts_flow_direction.argtypes = [C.c_void_p, _FP, C.c_float, C.c_float, _FP, C.c_int32, _FP]
+        L.ptts_op_linear.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int64, C.c_int64, _FP]
+        L.ptts_op_layernorm.argtypes = [_FP, _FP, _FP, C.c_float, C.c_int64, C.c_int64, _FP]
+        L.ptts_op_rope.argtypes = [_FP, _FP, _FP] + [C.c_int64] * 5
+        L.ptts_op_attention_positions.argtypes = [_FP, _FP, _FP] + [C.c_int64] * 5 + [_IP, _IP, C.c_int64, _FP]
+        L.ptts_op_conv1d_leftpad.argtypes = [_FP, _FP, _FP] + [C.c_int64] * 5 + [_FP]
+        L.ptts_op_convtr1d_righttrim.argtypes = [_FP, _FP, _FP] + [C.c_int64] * 7 + [_FP]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != PTTS_OK:
+        msg = lib().ptts_last_error().decode(errors="replace")
+        raise (Cancelled if rc == PTTS_ECANCELLED else PttsError)(rc, msg)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+def _fp(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(_FP) if a is not None else None
+
+
+def _ip(a: np.ndarray):
+    return a.ctypes.data_as(_IP)
+
+
+# ----------------------------------------------------------------------------- reference-shaped types
+
+@dataclass
+class VoiceEmbedding:
+    """tts.VoiceEmbedding (runtime.go:11-14): shape [1, T, D]."""
+    data: np.ndarray
+    shape: Sequence[int]
+
+
+@dataclass
+class VoiceModelState:
+    """safetensors.VoiceModelState (reader.go:29-31): modules[name]["cache" | "offset"]."""
+    modules: dict
+
+
+@dataclass
+class RuntimeGenerateConfig:
+    """tts.RuntimeGenerateConfig (runtime.go:17-31).  `noise` is this build's explicit form of the
+    reference's rng draws (flow_lm.go:386-408): [max_steps, 32] rows of N(0,1)*sqrt(temperature)."""
+    temperature: float = 0.0
+    eos_threshold: float = -4.0
+    max_steps: int = 0
+    estimated_max_steps: int = 0
+    lsd_decode_steps: int = 1
+    frames_after_eos: int = 0
+    mimi_steps_per_latent: int = 0   # accepted and ignored, like the native reference runtime
+    mimi_sequence_length: int = 0
+    voice_embedding: Optional[VoiceEmbedding] = None
+    voice_model_state: Optional[VoiceModelState] = None
+    step_callback: Optional[Callable[[int, int], None]] = None
+    noise: Optional[np.ndarray] = None
+    cancel: Optional[np.ndarray] = None  # int32[1]; nonzero = cancelled (the ctx of GenerateAudio)
+    want_latents: bool = False
+
+
+@dataclass
+class GenerateResult:
+    pcm: np.ndarray
+    n_frames: int
+    eos_step: int
+    latents: Optional[np.ndarray] = None
+
+
+@dataclass
+class ModelInfo:
+    d_model: int; n_heads: int; n_layers: int; ffn: int; ldim: int; n_bins: int
+    flow_dim: int; flow_depth: int; mimi_dim: int; mimi_heads: int; mimi_layers: int; mimi_context: int
+    sample_rate: int; samples_per_frame: int; steps_per_latent: int
+    frame_rate: float; encoder_frame_rate: float; n_params: int; arena_bytes: int; weights: int; kv: int
+
+
+def _opts(device=0, weights=WEIGHTS_F32, kv=KV_F32, max_batch=64, use_graph=True) -> _Opts:
+    o = _Opts()
+    lib().ptts_default_opts(C.byref(o))
+    o.device, o.weights, o.kv, o.max_batch, o.use_graph = device, weights, kv, max_batch, 1 if use_graph else 0
+    return o
+
+
+class Model:
+    """native.Model (internal/native/model.go:25-138) resident in HBM."""
+
+    def __init__(self, handle: int):
+        self.h = handle
+        i = _Info()
+        _check(lib().ptts_model_info(self.h, C.byref(i)))
+        self.info = ModelInfo(**{n: getattr(i, n) for n, _ in _Info._fields_})
+
+    @staticmethod
+    def open(path: str, **kw) -> "Model":
+        """LoadModelFromSafetensors (model.go:33-40)."""
+        h = C.c_void_p()
+        o = _opts(**kw)
+        _check(lib().ptts_model_open(path.encode(), C.byref(o), C.byref(h)))
+        return Model(h.value)
+
+    @staticmethod
+    def open_bytes(data: bytes, **kw) -> "Model":
+        """LoadModelFromStore over OpenStoreFromBytes (store.go:65)."""
+        h = C.c_void_p()
+        o = _opts(**kw)
+        buf = (C.c_char * len(data)).from_buffer_copy(data)
+        _check(lib().ptts_model_open_bytes(buf, len(data), C.byref(o), C.byref(h)))
+        return Model(h.value)
+
+    @staticmethod
+    def plan(path: str, **kw) -> tuple[int, int]:
+        """Returns (plan handle, arena bytes) for the two-phase multi-GPU open."""
+        p = C.c_void_p()
+        o = _opts(**kw)
+        _check(lib().ptts_plan_create(path.encode(), C.byref(o), C.byref(p)))
+        return p.value, int(lib().ptts_plan_arena_bytes(p.value))
+
+    @staticmethod
+    def open_planned(plan: int, device_arena_ptr: int, fill: bool) -> "Model":
+        h = C.c_void_p()
+        _check(lib().ptts_model_open_planned(plan, C.c_void_p(device_arena_ptr), 1 if fill else 0, C.byref(h)))
+        return Model(h.value)
+
+    def close(self):
+        if self.h:
+            lib().ptts_model_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # -- staged methods
+    def text_embeddings(self, ids) -> np.ndarray:
+        ids = np.ascontiguousarray(ids, np.int64)
+        out = np.empty((ids.size, self.info.d_model), np.float32)
+        _check(lib().ptts_text_embeddings(self.h, _ip(ids), ids.size, _fp(out)))
+        return out
+
+    def new_batch(self, n_slots: int, kv_capacity: int) -> "Batch":
+        return Batch(self, n_slots, kv_capacity)
+
+    def decode_latents(self, latents, want_mimi_latent: bool = False):
+        """LatentToMimi + MimiDecode (model.go:141,410): [n, frames, 32] -> pcm [n, frames*1920]."""
+        lat = _f32(latents)
+        if lat.ndim == 2:
+            lat = lat[None]
+        n, fr, _ = lat.shape
+        pcm = np.empty((n, fr * self.info.samples_per_frame), np.float32)
+        ml = np.empty((n, self.info.mimi_dim, fr), np.float32) if want_mimi_latent else None
+        _check(lib().ptts_decode_latents(self.h, _fp(lat), n, fr, _fp(pcm), _fp(ml)))
+        return (pcm, ml) if want_mimi_latent else pcm
+
+    def flow_direction(self, c, s: float, t: float, x) -> np.ndarray:
+        c = _f32(c).reshape(-1, self.info.d_model)
+        x = _f32(x).reshape(-1, self.info.ldim)
+        out = np.empty_like(x)
+        _check(lib().ptts_flow_direction(self.h, _fp(c), s, t, _fp(x), c.shape[0], _fp(out)))
+        return out
+
+    # -- batched GenerateAudio
+    def generate_batch(self, token_lists: Sequence[Sequence[int]], cfgs: Sequence[RuntimeGenerateConfig]) -> list[GenerateResult]:
+        n = len(token_lists)
+        reqs = (_Request * n)()
+        ress = (_Result * n)()
+        keep = []
+        for i, (toks, cfg) in enumerate(zip(token_lists, cfgs)):
+            t = np.ascontiguousarray(toks, np.int64)
+            keep.append(t)
+            r = reqs[i]
+            r.tokens, r.n_tokens = _ip(t), t.size
+            r.temperature, r.eos_threshold = cfg.temperature, min(cfg.eos_threshold, 3.0e38)
+            r.max_steps, r.estimated_max_steps = cfg.max_steps, cfg.estimated_max_steps
+            r.lsd_steps, r.frames_after_eos = cfg.lsd_decode_steps, cfg.frames_after_eos
+            if cfg.voice_embedding is not None:
+                ve = _f32(cfg.voice_embedding.data).reshape(-1, self.info.d_model)
+                keep.append(ve)
+                r.voice_embedding, r.voice_frames = _fp(ve), ve.shape[0]
+            if cfg.voice_model_state is not None:
+                ptrs, steps, offs, arrs = _voice_arrays(cfg.voice_model_state, self.info.n_layers)
+                keep += [ptrs, steps, offs, arrs]
+                r.voice_caches, r.voice_cache_steps, r.voice_offsets = ptrs, _ip(steps), _ip(offs)
+            if cfg.noise is not None:
+                nz = _f32(cfg.noise).reshape(-1, self.info.ldim)
+                keep.append(nz)
+                r.noise = _fp(nz)
+            if cfg.step_callback is not None:
+                cb = _STEP_CB(lambda _u, s, m, f=cfg.step_callback: f(s, m))
+                keep.append(cb)
+                r.step_callback = cb
+            if cfg.cancel is not None:
+                r.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
+            r.want_latents = 1 if cfg.want_latents else 0
+        rc = lib().ptts_generate(self.h, reqs, n, ress)
+        out = []
+        try:
+            _check(rc)
+            for i in range(n):
+                rs = ress[i]
+                pcm = np.ctypeslib.as_array(rs.pcm, (rs.n_samples,)).copy() if rs.n_samples else np.zeros(0, np.float32)
+                lat = None
+                if cfgs[i].want_latents:
+                    lat = np.ctypeslib.as_array(rs.latents, (rs.n_frames, self.info.ldim)).copy()
+                out.append(GenerateResult(pcm, int(rs.n_frames), int(rs.eos_step), lat))
+        finally:
+            for i in range(n):
+                lib().ptts_free_result(C.byref(ress[i]))
+        return out
+
+
+def _voice_arrays(state: VoiceModelState, n_layers: int):
+    caches, steps, offs = [], [], []
+    for i in range(n_layers):
+        name = f"transformer.layers.{i}.self_attn"  # flow_transformer.go:513-515
+        mod = state.modules.get(name)
+        if mod is None:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state missing module "{name}"')
+        if "cache" not in mod:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" missing cache')
+        if "offset" not in mod:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" missing offset')
+        c = _f32(mod["cache"])
+        if c.ndim != 5 or c.shape[0] != 2:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" cache shape {list(c.shape)}, want [2,B,T,H,D]')
+        if c.shape[1] != 1:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" batch {c.shape[1]}, want 1')
+        if c.shape[3] != 16 or c.shape[4] != 64:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" heads {c.shape[3]}, want 16')
+        off = np.asarray(mod["offset"], np.float32).reshape(-1)
+        if off.size == 0:
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" has empty offset tensor')
+        if np.float32(int(off[0])) != off[0]:  # flow_transformer.go:554-566
+            raise PttsError(PTTS_EINVAL, f'native: voice model state module "{name}" offset {off[0]} is not an integer')
+        caches.append(c)
+        steps.append(c.shape[2])
+        offs.append(int(off[0]))
+    ptrs = (_FP * n_layers)(*[_fp(c) for c in caches])
+    return ptrs, np.array(steps, np.int64), np.array(offs, np.int64), caches
+
+
+class Batch:
+    """n_slots x native.FlowLMState (flow_lm.go:45-49): NewFlowState / PromptFlow / SampleNextLatentStateful."""
+
+    def __init__(self, model: Model, n_slots: int, kv_capacity: int):
+        self.model, self.n = model, n_slots
+        h = C.c_void_p()
+        _check(lib().ptts_batch_new(model.h, n_slots, kv_capacity, C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if self.h:
+            lib().ptts_batch_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def reset(self):
+        _check(lib().ptts_batch_reset(self.h))
+
+    def set_voice_state(self, slot: int, state: VoiceModelState):
+        ptrs, steps, offs, arrs = _voice_arrays(state, self.model.info.n_layers)
+        _check(lib().ptts_batch_set_voice_state(self.h, slot, ptrs, _ip(steps), _ip(offs)))
+
+    def prompt(self, embs: Sequence[np.ndarray]):
+        """embs[s]: [T_s, d_model] rows for slot s (voice rows first, then text rows)."""
+        d = self.model.info.d_model
+        rows = [_f32(e).reshape(-1, d) for e in embs]
+        offs = np.zeros(self.n + 1, np.int64)
+        offs[1:] = np.cumsum([r.shape[0] for r in rows])
+        cat = np.concatenate(rows, 0) if offs[-1] else np.zeros((0, d), np.float32)
+        cat = np.ascontiguousarray(cat)
+        _check(lib().ptts_batch_prompt(self.h, _fp(cat), _ip(offs)))
+
+    def step(self, frames_in, lsd_steps: int = 1, noise=None):
+        m = self.model.info
+        fi = _f32(frames_in).reshape(self.n, m.ldim)
+        nz = _f32(noise).reshape(self.n, m.ldim) if noise is not None else None
+        fo = np.empty((self.n, m.ldim), np.float32)
+        eos = np.empty(self.n, np.float32)
+        last = np.empty((self.n, m.d_model), np.float32)
+        _check(lib().ptts_batch_step(self.h, _fp(fi), lsd_steps, _fp(nz), _fp(fo), _fp(eos), _fp(last)))
+        return fo, eos, last
+
+    def offsets(self) -> np.ndarray:
+        o = np.zeros(self.n, np.int64)
+        _check(lib().ptts_batch_offsets(self.h, _ip(o)))
+        return o
+
+    def read_kv(self, slot: int, layer: int):
+        n = int(self.offsets()[slot])
+        k = np.empty((self.model.info.n_heads, n, 64), np.float32)
+        v = np.empty_like(k)
+        _check(lib().ptts_batch_read_kv(self.h, slot, layer, _fp(k), _fp(v)))
+        return k, v
+
+
+class Runtime:
+    """tts.Runtime (runtime.go:42-45) on one MI355X: GenerateAudio + Close (+ MimiTiming)."""
+
+    def __init__(self, model: Model):
+        self.model = model
+
+    def generate_audio(self, tokens: Sequence[int], cfg: RuntimeGenerateConfig) -> np.ndarray:
+        """GenerateAudio (runtime_native_safetensors.go:52-238): returns f32 PCM @ 24 kHz."""
+        if self.model is None or self.model.h is None:
+            raise PttsError(PTTS_EINVAL, "native-safetensors runtime unavailable")
+        return self.model.generate_batch([tokens], [cfg])[0].pcm
+
+    def generate(self, tokens: Sequence[int], cfg: RuntimeGenerateConfig) -> GenerateResult:
+        if self.model is None or self.model.h is None:
+            raise PttsError(PTTS_EINVAL, "native-safetensors runtime unavailable")
+        return self.model.generate_batch([tokens], [cfg])[0]
+
+    def mimi_timing(self) -> tuple[float, float, int]:
+        """MimiTiming (runtime_native_safetensors.go:40-49): 12.5, 200, 16."""
+        i = self.model.info
+        return i.frame_rate, i.encoder_frame_rate, i.steps_per_latent
+
+    def close(self):
+        """Close (runtime_native_safetensors.go:240-244): nil-safe."""
+        if self.model is not None:
+            self.model.close()
+
+
+# ----------------------------------------------------------------------------- kernel-level entry points
+
+def op_linear(x, w, bias=None) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    out, inp = w.shape
+    rows = x.size // inp
+    y = np.empty(x.shape[:-1] + (out,), np.float32)
+    b = _f32(bias) if bias is not None else None
+    _check(lib().ptts_op_linear(_fp(x), _fp(w), _fp(b), rows, inp, out, _fp(y)))
+    return y
+
+
+def op_layernorm(x, w, b, eps: float) -> np.ndarray:
+    x = _f32(x)
+    d = x.shape[-1]
+    y = np.empty_like(x)
+    wa = _f32(w) if w is not None else None
+    ba = _f32(b) if b is not None else None
+    _check(lib().ptts_op_layernorm(_fp(x), _fp(wa), _fp(ba), eps, x.size // d, d, _fp(y)))
+    return y
+
+
+def op_rope(x, cos, sin, pos: int) -> np.ndarray:
+    x = _f32(x).copy()
+    cos, sin = _f32(cos), _f32(sin)
+    seq, dim = x.shape[-2], x.shape[-1]
+    _check(lib().ptts_op_rope(_fp(x), _fp(cos), _fp(sin), cos.shape[0], x.size // (seq * dim), seq, dim, pos))
+    return x
+
+
+def op_attention_positions(q, k, v, posq, posk, context: int) -> np.ndarray:
+    q, k, v = _f32(q), _f32(k), _f32(v)
+    b, h, tq, d = q.shape
+    tk = k.shape[2]
+    pq, pk = np.ascontiguousarray(posq, np.int64), np.ascontiguousarray(posk, np.int64)
+    out = np.empty((b, h, tq, d), np.float32)
+    _check(lib().ptts_op_attention_positions(_fp(q), _fp(k), _fp(v), b, h, tq, tk, d, _ip(pq), _ip(pk), context, _fp(out)))
+    return out
+
+
+def op_conv1d_leftpad(x, w, bias=None) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    b, cin, ln = x.shape
+    cout, _, k = w.shape
+    y = np.empty((b, cout, ln), np.float32)
+    ba = _f32(bias) if bias is not None else None
+    _check(lib().ptts_op_conv1d_leftpad(_fp(x), _fp(w), _fp(ba), b, cin, ln, cout, k, _fp(y)))
+    return y
+
+
+def op_convtr1d_righttrim(x, w, bias, stride: int, groups: int = 1) -> np.ndarray:
+    x, w = _f32(x), _f32(w)
+    b, cin, ln = x.shape
+    _, opg, k = w.shape
+    y = np.empty((b, opg * groups, ln * stride), np.float32)
+    ba = _f32(bias) if bias is not None else None
+    _check(lib().ptts_op_convtr1d_righttrim(_fp(x), _fp(w), _fp(ba), b, cin, ln, opg, k, stride, groups, _fp(y)))
+    return y

@@ -1,0 +1,174 @@
+/*
+ * ptts.h -- C ABI of libptts_hip.so: the MI355X-native PocketTTS synthesis path.
+ *
+ * Drop-in boundary.  The reference has no FFI; its seam is the Go interface
+ *     type Runtime interface { GenerateAudio(ctx, tokens []int64, cfg RuntimeGenerateConfig) ([]float32, error); Close() }
+ * (internal/tts/runtime.go:42-45) implemented by nativeSafetensorsRuntime
+ * (internal/tts/runtime_native_safetensors.go:20-244) on top of native.Model
+ * (internal/native/model.go:25-138).  The entry points below are exactly what a
+ * cgo binding of that seam needs; each one names the reference method it
+ * replaces.  INTEGRATION.md shows the cgo shim.
+ *
+ * Conventions (mirroring the reference's):
+ *   - every call returns 0 on success or a PTTS_E* code; the message is
+ *     ptts_last_error() (thread-local), worded like the reference's Go errors;
+ *   - no exceptions cross the ABI; inputs are borrowed and never mutated;
+ *   - outputs are library-allocated and released with ptts_free_result(), or
+ *     caller-allocated where a size is known up front;
+ *   - a model handle may be shared by threads; ptts_generate() calls on one
+ *     model are serialised on that model's HIP stream.
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with PTTS_ENODEVICE.
+ */
+#ifndef PTTS_H
+#define PTTS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTTS_OK          0
+#define PTTS_EINVAL      1   /* bad argument / shape / range (reference: fmt.Errorf paths) */
+#define PTTS_EIO         2   /* file cannot be read */
+#define PTTS_EFORMAT     3   /* not a valid safetensors / missing tensor */
+#define PTTS_ENODEVICE   4   /* no HIP device, or a HIP call failed */
+#define PTTS_ECANCELLED  5   /* ctx.Err() between steps (runtime_native_safetensors.go:156-159) */
+#define PTTS_ENOMEM      6
+
+/* how weights are held in HBM */
+#define PTTS_WEIGHTS_F32   0  /* as the reference holds them (every dtype decoded to f32, store.go:339-395) */
+#define PTTS_WEIGHTS_BF16  1  /* 2 bytes/param; exact when the file itself is BF16 */
+/* KV-cache element type */
+#define PTTS_KV_F32   0
+#define PTTS_KV_BF16  1
+
+typedef struct ptts_model ptts_model;
+typedef struct ptts_plan  ptts_plan;
+typedef struct ptts_batch ptts_batch;
+
+typedef struct ptts_opts {
+    int32_t device;          /* HIP device ordinal */
+    int32_t weights;         /* PTTS_WEIGHTS_* */
+    int32_t kv;              /* PTTS_KV_* */
+    int32_t max_batch;       /* utterances stepped together on the GPU (default 64) */
+    int32_t use_graph;       /* 1: the AR step is captured once into a hipGraph and replayed */
+    int32_t reserved[11];
+} ptts_opts;
+
+void ptts_default_opts(ptts_opts* o);
+
+typedef struct ptts_info {
+    int64_t d_model, n_heads, n_layers, ffn, ldim, n_bins;      /* flow_lm.go:13-27 */
+    int64_t flow_dim, flow_depth;                               /* flow_net.go:242-248 */
+    int64_t mimi_dim, mimi_heads, mimi_layers, mimi_context;    /* mimi.go:16-34 */
+    int64_t sample_rate, samples_per_frame, steps_per_latent;   /* MimiTiming(): runtime_native_safetensors.go:40-49 */
+    double  frame_rate, encoder_frame_rate;
+    int64_t n_params, arena_bytes;
+    int32_t weights, kv;
+} ptts_info;
+
+/* ---- model lifetime: native.LoadModelFromSafetensors / LoadModelFromStore / Model.Close
+ *      (internal/native/model.go:33-71) ---- */
+int  ptts_model_open(const char* safetensors_path, const ptts_opts* opts, ptts_model** out);
+int  ptts_model_open_bytes(const void* data, size_t len, const ptts_opts* opts, ptts_model** out);
+void ptts_model_close(ptts_model* m);                               /* nil-safe, like Model.Close */
+int  ptts_model_info(const ptts_model* m, ptts_info* out);
+const char* ptts_last_error(void);
+
+/* Two-phase open for multi-GPU start-up: every rank plans from the
+ * file header alone, allocates one device arena of ptts_plan_arena_bytes(), rank 0
+ * fills it (fill=1: decode, convert, derive tables, upload) and the arena is then
+ * broadcast once over RCCL/xGMI; the other ranks adopt it as is (fill=0). */
+int    ptts_plan_create(const char* safetensors_path, const ptts_opts* opts, ptts_plan** out);
+int    ptts_plan_create_bytes(const void* data, size_t len, const ptts_opts* opts, ptts_plan** out);
+size_t ptts_plan_arena_bytes(const ptts_plan* p);
+int    ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_model** out); /* consumes p */
+void   ptts_plan_free(ptts_plan* p);
+
+/* ---- the Runtime seam: tts.Runtime.GenerateAudio (runtime_native_safetensors.go:52-238) ---- */
+typedef void (*ptts_step_callback)(void* user, int32_t step, int32_t max_steps); /* RuntimeGenerateConfig.StepCallback */
+
+typedef struct ptts_request {
+    const int64_t* tokens; int64_t n_tokens;          /* must be non-empty (:57-59) */
+    float   temperature;                              /* only validates `noise`: <=0 means zero noise (flow_lm.go:395-404) */
+    float   eos_threshold;                            /* isEOS = logit > threshold (flow_lm.go:281) */
+    int32_t max_steps;                                /* <=0: estimated_max_steps, then EstimateMaxFrames (:61-67) */
+    int32_t estimated_max_steps;
+    int32_t lsd_steps;                                /* <=0 -> 1 (:69-72) */
+    int32_t frames_after_eos;                         /* text.FramesAfterEOS */
+    /* voice conditioning, mutually exclusive (:100-102) */
+    const float* voice_embedding; int64_t voice_frames;        /* [Tv, d_model], prepended (:104-119) */
+    const float* const* voice_caches;                           /* per layer [2,1,T,H,Dh] f32 (flow_transformer.go:451-552) */
+    const int64_t* voice_cache_steps;                           /* per layer T */
+    const int64_t* voice_offsets;                               /* per layer offset, 0 <= offset <= T */
+    /* sampling noise: [max_steps, ldim] = N(0,1)*sqrt(temperature) draws, one row per AR step,
+     * consumed as x0 of that step's LSD decode (flow_lm.go:283-288).  NULL = zeros. */
+    const float* noise;
+    ptts_step_callback step_callback; void* callback_user;
+    const volatile int32_t* cancel;                   /* polled between steps; nonzero -> PTTS_ECANCELLED */
+    int32_t want_latents;                             /* 1: also return the latent frames */
+    int32_t reserved[7];
+} ptts_request;
+
+typedef struct ptts_result {
+    float*  pcm;       int64_t n_samples;             /* fresh copy owned by the caller (:237) */
+    float*  latents;   int32_t n_frames;              /* [n_frames, ldim] when want_latents */
+    int32_t eos_step;                                 /* first step whose EOS logit crossed the threshold, -1 if none */
+    int32_t status;                                   /* per-request PTTS_* code */
+    int32_t reserved[4];
+} ptts_result;
+
+/* n_reqs == 1 reproduces GenerateAudio exactly.  n_reqs > 1 is this library's batching
+ * extension: independent utterance chunks stepped together (per-row EOS countdown, ragged KV). */
+int  ptts_generate(ptts_model* m, const ptts_request* reqs, int32_t n_reqs, ptts_result* results);
+void ptts_free_result(ptts_result* r);
+
+/* ---- staged entry points = the native.Model methods GenerateAudio calls (model.go:76-138,141,410).
+ *      A ptts_batch is n_slots independent FlowLMState objects (flow_lm.go:45-49) held in HBM. ---- */
+int  ptts_text_embeddings(ptts_model* m, const int64_t* ids, int64_t n, float* out /* [n, d_model] host */); /* Model.TextEmbeddings */
+int  ptts_batch_new(ptts_model* m, int32_t n_slots, int32_t kv_capacity, ptts_batch** out);                 /* Model.NewFlowState x n_slots */
+void ptts_batch_free(ptts_batch* b);
+int  ptts_batch_reset(ptts_batch* b);
+/* Model.NewFlowStateFromVoiceModelState for one slot */
+int  ptts_batch_set_voice_state(ptts_batch* b, int32_t slot, const float* const* caches,
+                                const int64_t* cache_steps, const int64_t* offsets);
+/* Model.PromptFlow for every slot at once: slot s gets emb + row_offsets[s] .. row_offsets[s+1] (rows of d_model floats, host) */
+int  ptts_batch_prompt(ptts_batch* b, const float* emb, const int64_t* row_offsets);
+/* Model.SampleNextLatentStateful for every slot: frames_in [n_slots, ldim] (NaN = BOS), noise NULL or [n_slots, ldim];
+ * outputs (host, caller-allocated, any may be NULL): frames_out [n_slots, ldim], eos_logits [n_slots], last_hidden [n_slots, d_model] */
+int  ptts_batch_step(ptts_batch* b, const float* frames_in, int32_t lsd_steps, const float* noise,
+                     float* frames_out, float* eos_logits, float* last_hidden);
+int  ptts_batch_offsets(ptts_batch* b, int64_t* out /* [n_slots] */);
+int  ptts_batch_read_kv(ptts_batch* b, int32_t slot, int32_t layer, float* k, float* v /* [H, offset, Dh] each */);
+/* Model.LatentToMimi + Model.MimiDecode: latents [n_utt, frames, ldim] host -> pcm [n_utt, frames*samples_per_frame] host;
+ * mimi_latent (optional) receives LatentToMimi's [n_utt, mimi_dim, frames] */
+int  ptts_decode_latents(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,
+                         float* pcm, float* mimi_latent);
+/* FlowLM.FlowDirection (flow_lm.go:302-308): c [n, d_model], x [n, ldim] -> out [n, ldim] */
+int  ptts_flow_direction(ptts_model* m, const float* c, float s, float t, const float* x, int32_t n, float* out);
+
+/* ---- kernel-level entry points (host buffers in/out) = internal/runtime/ops + tensor, backed by
+ *      the same HIP kernels the model path launches; they exist so that the reference's
+ *      known-answer tests can be replayed against the GPU kernels. ---- */
+int ptts_op_linear(const float* x, const float* w, const float* bias, int64_t rows, int64_t in, int64_t out, float* y);              /* tensor.Linear nn_ops.go:268 */
+int ptts_op_layernorm(const float* x, const float* w, const float* b, float eps, int64_t rows, int64_t d, float* y);                 /* tensor.LayerNorm nn_ops.go:79 */
+int ptts_op_rope(float* x /* [prefix, seq, dim] in place */, const float* cos_t, const float* sin_t, int64_t table_rows,
+                 int64_t prefix, int64_t seq, int64_t dim, int64_t pos);                                                              /* ops.RoPE rope.go:13 */
+int ptts_op_attention_positions(const float* q, const float* k, const float* v, int64_t b, int64_t h, int64_t tq, int64_t tk,
+                 int64_t d, const int64_t* posq, const int64_t* posk, int64_t context, float* out);                                  /* ops.AttentionWithPositions attention.go:63 */
+int ptts_op_conv1d_leftpad(const float* x /* [B,Cin,L] */, const float* w /* [Cout,Cin,k] */, const float* bias,
+                 int64_t b, int64_t cin, int64_t len, int64_t cout, int64_t k, float* y /* [B,Cout,L] */);                           /* ops.Conv1DLeftPad conv1d.go:95 (stride 1, leftPad k-1) */
+int ptts_op_convtr1d_righttrim(const float* x /* [B,Cin,L] */, const float* w /* [Cin,Cout/groups,k] */, const float* bias,
+                 int64_t b, int64_t cin, int64_t len, int64_t cout_per_group, int64_t k, int64_t stride, int64_t groups,
+                 float* y /* [B,Cout,L*stride] */);                                                                                  /* ops.ConvTranspose1DRightTrim convtranspose1d.go:213 (k = 2*stride, trim k-stride; groups 1 or Cin) */
+
+/* build/version string, e.g. "ptts-hip 0.1 gfx950" */
+const char* ptts_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PTTS_H */

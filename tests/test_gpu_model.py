@@ -1,0 +1,378 @@
+"""GPU parity, model level: the HIP path (through the C ABI) against the CPU oracle on synthetic
+checkpoints with the reference's tensor names and shapes.
+
+Tolerances are the reference's own model-level targets (internal/native/python_parity_test.go:86,119-120):
+flow step abs 2e-4 / rel 5e-3, latent->mimi abs 2e-4 / rel 1e-3, decode abs 2e-4 / rel 5e-2, with the
+reference's metric (native/parity.go:20-70: max abs error and max relative error) -- except that the relative
+error is evaluated on elements with |want| >= 1e-3 * max|want| (a relative error on a value that is itself
+rounding noise says nothing).  Integer outputs (frame counts, EOS step, cache offsets) must match exactly.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FLOW_TOL = (2e-4, 5e-3)
+CONV_TOL = (2e-4, 1e-3)
+DECONV_TOL = (2e-4, 5e-2)
+
+
+def parity(name, got, want, tol, scale_abs=True):
+    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    assert np.isfinite(got).all(), f"{name}: non-finite output"
+    err = np.abs(got - want)
+    ref = max(1.0, np.abs(want).max()) if scale_abs else 1.0
+    big = np.abs(want) >= 1e-3 * np.abs(want).max()
+    rel = (err[big] / np.abs(want[big])).max() if big.any() else 0.0
+    assert err.max() <= tol[0] * ref and rel <= tol[1], f"{name}: max abs {err.max():.3e} (scale {ref:.2f}) max rel {rel:.3e} tol {tol}"
+    return err.max(), rel
+
+
+def det(shape, scale):
+    """deterministic_tensor of scripts/dump_python_parity.py:173-179: ((i % 23) - 11) * scale"""
+    n = int(np.prod(shape))
+    return (((np.arange(n) % 23) - 11) * scale).astype(np.float32).reshape(shape)
+
+
+@pytest.fixture(scope="module")
+def tiny(pkg, tmp_path_factory):
+    synth = pkg.synth
+    cfg = synth.SynthConfig.tiny()
+    path = str(tmp_path_factory.mktemp("ckpt") / "tiny.safetensors")
+    synth.write_safetensors(path, synth.make_checkpoint(cfg, seed=1234))
+    om = O.OracleModel.from_file(path)
+    gm = pkg.Model.open(path, device=0)
+    yield cfg, path, om, gm
+    gm.close()
+
+
+def test_model_info_and_timing(pkg, tiny):
+    cfg, _, om, gm = tiny
+    i = gm.info
+    assert (i.d_model, i.n_heads, i.n_layers, i.ldim, i.flow_dim, i.flow_depth, i.mimi_dim) == \
+           (om.d_model, om.heads, om.n_layers, om.ldim, om.flow_dim, om.flow_depth, om.mimi_dim)
+    assert i.n_bins == cfg.n_bins + 1
+    assert pkg.Runtime(gm).mimi_timing() == (12.5, 200.0, 16)   # runtime_native_safetensors.go:40-49
+    assert i.samples_per_frame == 1920 and i.sample_rate == 24000
+
+
+def test_text_embeddings_exact(pkg, tiny):
+    _, _, om, gm = tiny
+    ids = [10, 20, 30, 0, 63]
+    assert np.array_equal(gm.text_embeddings(ids), om.text_embeddings(ids))          # a gather is bit-exact
+    with pytest.raises(pkg.PttsError, match=r"token id 1 \(64\) out of range \[0,64\)"):  # conditioner.go:41-45
+        gm.text_embeddings([1, 64])
+    with pytest.raises(pkg.PttsError, match="out of range"):
+        gm.text_embeddings([-1])
+
+
+def test_prefill_kv_and_step_parity(pkg, tiny):
+    """python_parity_test.go:40-104 shape: tokens 10,20,30 -> prompt offsets, one step, last_hidden / eos logits."""
+    _, _, om, gm = tiny
+    toks = [10, 20, 30]
+    emb = om.text_embeddings(toks)
+    st = om.new_state()
+    om.prompt(st, emb)
+    b = gm.new_batch(1, 64)
+    b.prompt([emb])
+    assert list(b.offsets()) == [3] and st.offset(0) == 3
+    for layer in range(om.n_layers):
+        ko, vo = st.kv(layer)
+        kg, vg = b.read_kv(0, layer)
+        parity(f"prefill K layer {layer}", kg, ko, FLOW_TOL)
+        parity(f"prefill V layer {layer}", vg, vo, FLOW_TOL)
+    step_latent = det((1, 32), 0.05)
+    fo, is_eos, logit, last = om.step(st, step_latent[0])
+    gfo, geos, glast = b.step(step_latent)
+    assert list(b.offsets()) == [4] and st.offset(0) == 4
+    parity("step last_hidden", glast[0], last, FLOW_TOL)
+    parity("step eos_logit", geos[:1], [logit], FLOW_TOL)
+    parity("step frame", gfo[0], fo, FLOW_TOL)
+    # BOS: an all-NaN frame is replaced by bos_emb (tensor_util.go:259-268)
+    bos = np.full((1, 32), np.nan, np.float32)
+    fo2, _, logit2, last2 = om.step(st, bos[0])
+    gfo2, geos2, glast2 = b.step(bos)
+    parity("bos step last_hidden", glast2[0], last2, FLOW_TOL)
+    parity("bos step frame", gfo2[0], fo2, FLOW_TOL)
+    b.close()
+
+
+def test_step_with_noise_and_multiple_lsd_steps(tiny):
+    _, _, om, gm = tiny
+    emb = om.text_embeddings([5, 6, 7, 8])
+    rng = np.random.default_rng(0)
+    for lsd in (1, 2, 4):
+        st = om.new_state()
+        om.prompt(st, emb)
+        b = gm.new_batch(1, 64)
+        b.prompt([emb])
+        frame = np.full((1, 32), np.nan, np.float32)
+        for _ in range(3):
+            noise = (rng.standard_normal((1, 32)) * np.sqrt(0.7)).astype(np.float32)
+            fo, _, logit, last = om.step(st, frame[0], lsd_steps=lsd, noise=noise[0])
+            gfo, geos, glast = b.step(frame, lsd_steps=lsd, noise=noise)
+            parity(f"lsd={lsd} frame", gfo[0], fo, FLOW_TOL)
+            parity(f"lsd={lsd} eos", geos[:1], [logit], FLOW_TOL)
+            frame = fo[None]
+        b.close()
+
+
+def test_flow_direction_parity(tiny):
+    _, _, om, gm = tiny
+    rng = np.random.default_rng(1)
+    c = rng.standard_normal((3, om.d_model)).astype(np.float32)
+    x = rng.standard_normal((3, 32)).astype(np.float32)
+    got = gm.flow_direction(c, 0.25, 0.75, x)
+    want = np.stack([om.flow_direction(c[i], 0.25, 0.75, x[i]) for i in range(3)])
+    parity("flow_direction", got, want, FLOW_TOL)
+
+
+@pytest.mark.parametrize("frames", [1, 2, 4])
+def test_latent_to_mimi_and_decode_parity(tiny, frames):
+    """python_parity_test.go:106-158: deterministic latents of 1 / 2 / 4 frames."""
+    _, _, om, gm = tiny
+    latent = det((1, frames, 32), 0.03)
+    pcm, ml = gm.decode_latents(latent, want_mimi_latent=True)
+    want_ml = om.latent_to_mimi(latent[0])
+    parity("latent_to_mimi", ml[0], want_ml, CONV_TOL)
+    want_pcm = om.mimi_decode(want_ml)
+    assert pcm.shape == (1, frames * 1920)
+    parity("mimi_decode", pcm[0], want_pcm, DECONV_TOL)
+
+
+def test_decode_is_causal_so_padding_to_longest_is_exact(tiny):
+    """The batch path decodes every utterance to the longest length and truncates; valid because every decoder
+    op is causal (mimi.go:69-76,116-125,418)."""
+    _, _, om, gm = tiny
+    rng = np.random.default_rng(2)
+    lat = rng.standard_normal((2, 5, 32)).astype(np.float32) * 0.5
+    full = gm.decode_latents(lat)
+    short = gm.decode_latents(lat[:, :3])
+    assert np.array_equal(full[:, : 3 * 1920], short)
+
+
+def test_mimi_context_window_long_sequence(tiny):
+    """17 frames = 272 decoder steps > context 250: exercises the sliding window (mimi.go:32,418)."""
+    _, _, om, gm = tiny
+    rng = np.random.default_rng(4)
+    lat = (rng.standard_normal((1, 17, 32)) * 0.5).astype(np.float32)
+    pcm = gm.decode_latents(lat)
+    want = om.mimi_decode(om.latent_to_mimi(lat[0]))
+    parity("mimi_decode 17 frames", pcm[0], want, DECONV_TOL)
+
+
+def test_generate_matches_oracle_fixed_length(pkg, tiny):
+    _, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    toks = [10, 20, 30]
+    cfg = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=6, frames_after_eos=3, want_latents=True)
+    got = rt.generate(toks, cfg)
+    ref = om.generate(toks, max_steps=6, eos_threshold=1e30, frames_after_eos=3)
+    assert got.n_frames == ref["n_frames"] == 6 and got.eos_step == ref["eos_step"] == -1
+    parity("latents", got.latents, ref["latents"], (2e-3, 5e-2))     # 6 autoregressive steps of accumulated rounding
+    parity("pcm", got.pcm, ref["pcm"], (5e-3, 2e-1))
+    assert got.pcm.shape == (6 * 1920,)
+    # GenerateAudio returns the PCM alone
+    assert np.array_equal(rt.generate_audio(toks, cfg), got.pcm)
+    # graph replay and eager launches are the same computation
+    gm2 = pkg.Model.open(tiny[1], device=0, use_graph=False)
+    got2 = pkg.Runtime(gm2).generate(toks, cfg)
+    assert np.array_equal(got2.latents, got.latents) and np.array_equal(got2.pcm, got.pcm)
+    gm2.close()
+
+
+def _eos_case(om, toks, max_steps, fae):
+    """Pick a threshold between observed logits so that EOS fires at a chosen step."""
+    ref = om.generate(toks, max_steps=max_steps, eos_threshold=1e30, frames_after_eos=fae)
+    st = om.new_state()
+    om.prompt(st, om.text_embeddings(toks))
+    frame = np.full(32, np.nan, np.float32)
+    logits = []
+    for _ in range(max_steps):
+        frame, _, lg, _ = om.step(st, frame)
+        logits.append(lg)
+    return ref, np.array(logits)
+
+
+def test_eos_countdown_semantics_exact(pkg, tiny):
+    """runtime_native_safetensors.go:176-190: the EOS step's frame is kept, then exactly frames_after_eos more."""
+    _, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    toks = [1, 2, 3, 4, 5]
+    _, logits = _eos_case(om, toks, 12, 3)
+    order = np.argsort(logits)
+    k = int(order[-1])                      # the step with the largest logit crosses first if it is also the earliest above thr
+    thr = float(logits[k]) - 1e-3
+    first = int(np.argmax(logits > thr))
+    for fae in (0, 2, 5):
+        ref = om.generate(toks, max_steps=12, eos_threshold=thr, frames_after_eos=fae)
+        got = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=thr, max_steps=12, frames_after_eos=fae, want_latents=True))
+        assert ref["eos_step"] == first
+        assert got.eos_step == ref["eos_step"]
+        assert got.n_frames == ref["n_frames"] == min(12, first + fae + 1)
+        assert got.pcm.shape[0] == got.n_frames * 1920
+
+
+def test_step_limit_resolution(pkg, tiny):
+    """MaxSteps -> EstimatedMaxSteps -> EstimateMaxFrames(len(tokens)) (runtime_native_safetensors.go:61-67)."""
+    _, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    toks = [3, 4, 5]
+    got = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=0, estimated_max_steps=4))
+    assert got.n_frames == 4
+    got = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=2, estimated_max_steps=4))
+    assert got.n_frames == 2
+
+
+def test_generate_errors_match_reference_wording(pkg, tiny):
+    _, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    cfg = pkg.RuntimeGenerateConfig(max_steps=2)
+    with pytest.raises(pkg.PttsError, match="generate: token slice must not be empty"):
+        rt.generate_audio([], cfg)
+    with pytest.raises(pkg.PttsError, match="generate: text embeddings: native: token id 0"):
+        rt.generate_audio([9999], cfg)
+    ve = pkg.VoiceEmbedding(np.zeros((1, 2, om.d_model), np.float32), [1, 2, om.d_model])
+    vs = pkg.VoiceModelState(_modules(pkg.synth.make_voice_state(tiny[0], offset=4)))
+    with pytest.raises(pkg.PttsError, match="mutually exclusive"):
+        rt.generate_audio([1], pkg.RuntimeGenerateConfig(max_steps=2, voice_embedding=ve, voice_model_state=vs))
+
+
+def _modules(tensors):
+    """loadVoiceModelStateFromStore (reader.go:273-308) on in-memory tensors."""
+    mods = {}
+    for name, t in tensors.items():
+        mod, key = name.rsplit("/", 1)
+        if key == "current_end":
+            key, t = "offset", np.array([float(t.shape[0])], np.float32)
+        mods.setdefault(mod, {})[key] = np.asarray(t, np.float32)
+    return mods
+
+
+def test_voice_embedding_is_prepended(pkg, tiny):
+    cfg, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    ve = pkg.synth.make_voice_embedding(cfg, frames=7)["audio_prompt"]
+    toks = [7, 8, 9]
+    ref = om.generate(toks, max_steps=4, eos_threshold=1e30, frames_after_eos=3, voice_emb=ve[0])
+    got = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=4, want_latents=True,
+                                                      voice_embedding=pkg.VoiceEmbedding(ve, list(ve.shape))))
+    assert got.n_frames == ref["n_frames"] == 4
+    parity("latents (voice embedding)", got.latents, ref["latents"], (2e-3, 5e-2))
+    base = om.generate(toks, max_steps=4, eos_threshold=1e30, frames_after_eos=3)
+    assert np.abs(base["latents"] - ref["latents"]).max() > 1e-2     # conditioning changes the output
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_voice_model_state_with_nan_padding(pkg, tiny, legacy):
+    """Stock voices are KV snapshots [2,1,T,16,64] with NaN beyond `offset` (export_onnx.py:96-121); never read them."""
+    cfg, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    tens = pkg.synth.make_voice_state(cfg, offset=9, capacity=(9 if legacy else 16), legacy_current_end=legacy)
+    mods = _modules(tens)
+    toks = [11, 12]
+    ref = om.generate(toks, max_steps=4, eos_threshold=1e30, frames_after_eos=3, voice_state=mods)
+    got = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=4, want_latents=True,
+                                                      voice_model_state=pkg.VoiceModelState(mods)))
+    assert got.n_frames == 4
+    parity("latents (voice state)", got.latents, ref["latents"], (2e-3, 5e-2))
+    parity("pcm (voice state)", got.pcm, ref["pcm"], (5e-3, 2e-1))
+
+
+def test_voice_state_guards(pkg, tiny):
+    cfg, _, om, gm = tiny
+    b = gm.new_batch(1, 32)
+    mods = _modules(pkg.synth.make_voice_state(cfg, offset=4, capacity=4))
+    mods["transformer.layers.0.self_attn"]["offset"] = np.array([5.0], np.float32)       # flow_transformer.go:547-549
+    with pytest.raises(pkg.PttsError, match="exceeds cache length"):
+        b.set_voice_state(0, pkg.VoiceModelState(mods))
+    mods["transformer.layers.0.self_attn"]["offset"] = np.array([2.5], np.float32)       # :554-566
+    with pytest.raises(pkg.PttsError, match="is not an integer"):
+        b.set_voice_state(0, pkg.VoiceModelState(mods))
+    del mods["transformer.layers.1.self_attn"]
+    with pytest.raises(pkg.PttsError, match="missing module"):
+        b.set_voice_state(0, pkg.VoiceModelState(mods))
+    b.close()
+
+
+def test_ragged_batch_equals_single_requests(pkg, tiny):
+    """The batching extension: n_reqs > 1 must give every utterance exactly what n_reqs == 1 gives it
+    (different prompt lengths, step budgets, EOS thresholds, voices)."""
+    cfg, _, om, gm = tiny
+    vs = pkg.VoiceModelState(_modules(pkg.synth.make_voice_state(cfg, offset=6)))
+    ve_arr = pkg.synth.make_voice_embedding(cfg, frames=3)["audio_prompt"]
+    ve = pkg.VoiceEmbedding(ve_arr, list(ve_arr.shape))
+    toks = [[1, 2, 3], [4, 5, 6, 7, 8, 9, 10], [11], [12, 13]]
+    _, logits = _eos_case(om, toks[1], 8, 2)
+    thr = float(np.sort(logits)[-2])        # second-largest logit: EOS fires where the largest one is
+    cfgs = [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=5, want_latents=True),
+            pkg.RuntimeGenerateConfig(eos_threshold=thr, max_steps=8, frames_after_eos=2, want_latents=True),
+            pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=3, want_latents=True, voice_model_state=vs),
+            pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=7, want_latents=True, voice_embedding=ve)]
+    batch = gm.generate_batch(toks, cfgs)
+    for i in range(4):
+        one = gm.generate_batch([toks[i]], [cfgs[i]])[0]
+        assert batch[i].n_frames == one.n_frames and batch[i].eos_step == one.eos_step
+        parity(f"batch vs single latents {i}", batch[i].latents, one.latents, (1e-5, 1e-3))
+        parity(f"batch vs single pcm {i}", batch[i].pcm, one.pcm, (1e-5, 1e-2))
+    ref1 = om.generate(toks[1], max_steps=8, eos_threshold=thr, frames_after_eos=2)
+    assert batch[1].n_frames == ref1["n_frames"] and batch[1].eos_step == ref1["eos_step"]
+
+
+def test_step_callback_and_cancel(pkg, tiny):
+    _, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    seen = []
+    cfg = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=5, step_callback=lambda s, m: seen.append((s, m)))
+    rt.generate_audio([1, 2], cfg)
+    assert seen == [(i, 5) for i in range(1, 6)]        # called after every step of `for step := range maxSteps`
+    flag = np.ones(1, np.int32)
+    with pytest.raises(pkg.Cancelled):
+        rt.generate_audio([1, 2], pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=5, cancel=flag))
+
+
+def test_bf16_checkpoint_same_values_as_reference_reader(pkg, tiny, tmp_path):
+    """A BF16 file is decoded to f32 by the reference (store.go:370-379); holding the weights as bf16 in HBM is exact,
+    and the oracle on the same file is the reference-equivalent result."""
+    cfg = tiny[0]
+    synth = pkg.synth
+    path = str(tmp_path / "tiny_bf16.safetensors")
+    synth.write_safetensors(path, synth.make_checkpoint(cfg, seed=1234), dtype="BF16")
+    om = O.OracleModel.from_file(path)
+    toks = [10, 20, 30]
+    ref = om.generate(toks, max_steps=5, eos_threshold=1e30, frames_after_eos=3)
+    for weights, kv, tol_l, tol_p in ((pkg.WEIGHTS_F32, pkg.KV_F32, (2e-3, 5e-2), (5e-3, 2e-1)),
+                                      (pkg.WEIGHTS_BF16, pkg.KV_F32, (2e-3, 5e-2), (5e-3, 2e-1)),
+                                      (pkg.WEIGHTS_BF16, pkg.KV_BF16, (3e-2, 3e-1), (5e-2, 5e-1))):
+        gm = pkg.Model.open(path, device=0, weights=weights, kv=kv)
+        got = pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=5, want_latents=True))
+        assert got.n_frames == 5
+        parity(f"latents w={weights} kv={kv}", got.latents, ref["latents"], tol_l)
+        parity(f"pcm w={weights} kv={kv}", got.pcm, ref["pcm"], tol_p)
+        gm.close()
+
+
+def test_two_phase_open_adopts_prefilled_arena(pkg, tiny):
+    """Multi-GPU start-up path: plan -> external arena -> fill on one model, adopt on another."""
+    import torch
+    _, path, om, gm = tiny
+    plan, nbytes = pkg.Model.plan(path)
+    arena = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    m1 = pkg.Model.open_planned(plan, arena.data_ptr(), fill=True)
+    plan2, nbytes2 = pkg.Model.plan(path)
+    assert nbytes2 == nbytes
+    arena2 = arena.clone()                       # stands in for the RCCL broadcast
+    torch.cuda.synchronize()
+    m2 = pkg.Model.open_planned(plan2, arena2.data_ptr(), fill=False)
+    cfg = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=3, want_latents=True)
+    a = pkg.Runtime(m1).generate([1, 2, 3], cfg)
+    b = pkg.Runtime(m2).generate([1, 2, 3], cfg)
+    c = pkg.Runtime(gm).generate([1, 2, 3], cfg)
+    assert np.array_equal(a.pcm, b.pcm) and np.array_equal(a.pcm, c.pcm)
+    m1.close()
+    m2.close()
