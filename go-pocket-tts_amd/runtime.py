@@ -12,6 +12,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import subprocess
+import sys
 from dataclasses import dataclass, field
 from typing import Callable, Optional, Sequence
 
@@ -93,6 +94,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PttsError(PTTS_ENODEVICE, f"{LIB_PATH} is missing: run __graft_entry__.build() (no CPU fallback exists)")
+        # PyTorch-ROCm bundles its own libamdhip64.so.7 / libhsa-runtime64; two HSA runtimes in one process leave the
+        # second without a GPU.  Importing torch first makes the dynamic linker resolve our DT_NEEDED libamdhip64.so.7
+        # to the copy torch already loaded, so tests / bench.py (torch.distributed plumbing) and this library share one
+        # runtime.  Hosts that never load torch (the Go service) set PTTS_NO_TORCH_PRELOAD=1 or simply lack torch.
+        if "torch" not in sys.modules and not os.environ.get("PTTS_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except Exception:  # noqa: BLE001
+                pass
         L = C.CDLL(LIB_PATH)
         L.ptts_last_error.restype = C.c_char_p
         L.ptts_version.restype = C.c_char_p
@@ -251,6 +261,8 @@ class Model:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():   # the HIP runtime may already be gone at interpreter teardown
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001
@@ -379,6 +391,8 @@ class Batch:
             self.h = None
 
     def __del__(self):
+        if sys.is_finalizing():   # the HIP runtime may already be gone at interpreter teardown
+            return
         try:
             self.close()
         except Exception:  # noqa: BLE001

@@ -28,8 +28,8 @@ def parity(name, got, want, tol, scale_abs=True):
     err = np.abs(got - want)
     ref = max(1.0, np.abs(want).max()) if scale_abs else 1.0
     big = np.abs(want) >= 1e-3 * np.abs(want).max()
-    rel = (err[big] / np.abs(want[big])).max() if big.any() else 0.0
-    assert err.max() <= tol[0] * ref and rel <= tol[1], f"{name}: max abs {err.max():.3e} (scale {ref:.2f}) max rel {rel:.3e} tol {tol}"
+    rel = (err[big] / np.abs(want[big])).max() if big.any() and tol[1] is not None else 0.0
+    assert err.max() <= tol[0] * ref and (tol[1] is None or rel <= tol[1]), f"{name}: max abs {err.max():.3e} (scale {ref:.2f}) max rel {rel:.3e} tol {tol}"
     return err.max(), rel
 
 
@@ -294,6 +294,7 @@ def test_voice_state_guards(pkg, tiny):
     mods["transformer.layers.0.self_attn"]["offset"] = np.array([2.5], np.float32)       # :554-566
     with pytest.raises(pkg.PttsError, match="is not an integer"):
         b.set_voice_state(0, pkg.VoiceModelState(mods))
+    mods["transformer.layers.0.self_attn"]["offset"] = np.array([4.0], np.float32)
     del mods["transformer.layers.1.self_attn"]
     with pytest.raises(pkg.PttsError, match="missing module"):
         b.set_voice_state(0, pkg.VoiceModelState(mods))
@@ -348,7 +349,7 @@ def test_bf16_checkpoint_same_values_as_reference_reader(pkg, tiny, tmp_path):
     ref = om.generate(toks, max_steps=5, eos_threshold=1e30, frames_after_eos=3)
     for weights, kv, tol_l, tol_p in ((pkg.WEIGHTS_F32, pkg.KV_F32, (2e-3, 5e-2), (5e-3, 2e-1)),
                                       (pkg.WEIGHTS_BF16, pkg.KV_F32, (2e-3, 5e-2), (5e-3, 2e-1)),
-                                      (pkg.WEIGHTS_BF16, pkg.KV_BF16, (3e-2, 3e-1), (5e-2, 5e-1))):
+                                      (pkg.WEIGHTS_BF16, pkg.KV_BF16, (3e-2, None), (2e-2, None))):   # bf16 KV: 8-bit mantissa keys/values, max-norm bound only
         gm = pkg.Model.open(path, device=0, weights=weights, kv=kv)
         got = pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=5, want_latents=True))
         assert got.n_frames == 5
