@@ -12,6 +12,7 @@ using namespace ptts;
 struct ptts_model { Model* m; };
 struct ptts_plan { Plan p; };
 struct ptts_batch { Batch* b; Model* m; };
+// ptts_voice is ptts::Voice (opaque to C)
 
 namespace {
 
@@ -172,6 +173,54 @@ void ptts_free_result(ptts_result* r) {
     r->latents = nullptr;
     r->n_samples = 0;
     r->n_frames = 0;
+}
+
+int ptts_voice_create(ptts_model* h, const float* const* caches, const int64_t* steps, const int64_t* offsets, ptts_voice** out) {
+    return guard([&] {
+        if (!h || !h->m || !out) throw Error(PTTS_EINVAL, "native: model flow_lm unavailable");
+        if (!caches || !steps || !offsets) throw Error(PTTS_EINVAL, "native: voice model state is nil");
+        std::lock_guard<std::mutex> lock(h->m->mu);
+        h->m->use_device();
+        *out = reinterpret_cast<ptts_voice*>(voice_create(*h->m, caches, steps, offsets));
+    });
+}
+
+void ptts_voice_free(ptts_voice* v) {
+    if (!v) return;
+    Voice* vv = reinterpret_cast<Voice*>(v);
+    (void)hipSetDevice(vv->m->device);
+    delete vv;
+}
+
+int ptts_profile_enable(ptts_model* h, int32_t on) {
+    return guard([&] {
+        if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
+        std::lock_guard<std::mutex> lock(h->m->mu);
+        h->m->prof.on = on != 0;
+        h->m->prof.used = 0; h->m->prof.bytes = 0; h->m->prof.launches = 0;
+    });
+}
+
+int ptts_profile_read(ptts_model* h, ptts_profile* out) {
+    return guard([&] {
+        if (!h || !h->m || !out) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
+        Model& m = *h->m;
+        std::lock_guard<std::mutex> lock(m.mu);
+        m.use_device();
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+        std::memset(out, 0, sizeof *out);
+        double ms = 0;
+        for (size_t i = 0; i + 1 < m.prof.used; i += 2) {
+            float t = 0;
+            PTTS_HIP(hipEventElapsedTime(&t, m.prof.ev[i], m.prof.ev[i + 1]));
+            ms += t;
+        }
+        out->launches = m.prof.launches;
+        out->total_ms = ms;
+        out->algorithmic_bytes = m.prof.bytes;
+        snprintf(out->kernel, sizeof out->kernel, "%s", "k_gemm");
+        m.prof.used = 0; m.prof.bytes = 0; m.prof.launches = 0;
+    });
 }
 
 int ptts_text_embeddings(ptts_model* h, const int64_t* ids, int64_t n, float* out) {

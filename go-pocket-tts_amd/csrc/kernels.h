@@ -112,6 +112,9 @@ void launch_upsample_depthwise(const float* in, const float* w0, const float* w1
 // voice model-state ingestion (flow_transformer.go:568-631): raw [2,1,T,H,D] f32 -> first `offset` rows of a slot's K and V cache
 void launch_voice_scatter(const float* raw, int t, int heads, int hd, int offset, int slot, void* kcache, void* vcache,
                           int kv_bf16, int64_t cap, hipStream_t stream);
+// copies a compact device voice (K, V as [H][offset][hd] in the cache dtype) into the first `offset` rows of several slots
+void launch_voice_apply(const void* vk, const void* vv, int offset, int heads, int hd, const int32_t* slots, int n_slots,
+                        void* kcache, void* vcache, int elem_bytes, int64_t cap, hipStream_t stream);
 // final causal conv Cin -> 1, kernel k, ELU on the input (mimi.go:781-783): in [B][pad+T][C] channels-last
 void launch_conv_final(const float* in, int in_pad_rows, const float* w /*[k*C]*/, const float* bias, int b, int t, int c,
                        int k, float* out /*[B][T]*/, hipStream_t stream);

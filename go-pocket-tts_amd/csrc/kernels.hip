@@ -603,6 +603,29 @@ void launch_voice_scatter(const float* raw, int t, int heads, int hd, int offset
     else hipLaunchKernelGGL(k_voice_scatter<false>, g, dim3(256), 0, stream, raw, t, heads, hd, offset, slot, kcache, vcache, cap);
 }
 
+__global__ void k_voice_apply(const uint4* vk, const uint4* vv, int offset, int heads, int row16, const int32_t* slots, int n_slots,
+                              uint4* kc, uint4* vc, int64_t cap) {
+    int64_t per_slot = (int64_t)heads * offset * row16;   // 16-byte chunks per slot
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_slot * n_slots) return;
+    int si = (int)(i / per_slot);
+    int64_t r = i % per_slot;
+    int c = (int)(r % row16);
+    int row = (int)((r / row16) % offset);
+    int h = (int)(r / ((int64_t)row16 * offset));
+    int64_t dst = (((int64_t)slots[si] * heads + h) * cap + row) * row16 + c;
+    kc[dst] = vk[r];
+    vc[dst] = vv[r];
+}
+void launch_voice_apply(const void* vk, const void* vv, int offset, int heads, int hd, const int32_t* slots, int n_slots,
+                        void* kcache, void* vcache, int elem_bytes, int64_t cap, hipStream_t stream) {
+    int row16 = hd * elem_bytes / 16;
+    int64_t tot = (int64_t)heads * offset * row16 * n_slots;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(k_voice_apply, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, (const uint4*)vk, (const uint4*)vv, offset,
+                       heads, row16, slots, n_slots, (uint4*)kcache, (uint4*)vcache, cap);
+}
+
 // K16 (last layer): ELU then causal conv C -> 1 (mimi.go:781-783); window of k rows is one contiguous span
 __global__ void k_conv_final(const float* in, int pad, const float* w, const float* bias, int b, int t, int c, int k, float* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

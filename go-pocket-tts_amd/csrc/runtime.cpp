@@ -45,6 +45,7 @@ static void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
 // Model
 // ------------------------------------------------------------------------------------------------
 Model::~Model() {
+    for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
     cached_batch.reset();
     tcomb.clear();
     ws.clear();
@@ -180,17 +181,56 @@ void batch_reset(Batch& b) {
     b.has_noise = false;
 }
 
-void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64_t* steps, const int64_t* offsets) {
-    Model& m = *b.m;
-    const Desc& d = m.d;
-    if (slot < 0 || slot >= b.B) throw Error(PTTS_EINVAL, "ptts-hip: voice state slot out of range");
+static void check_voice(const Desc& d, const float* const* caches, const int64_t* steps, const int64_t* offsets, int64_t cap) {
     for (int l = 0; l < d.n_layers; l++) {  // flow_transformer.go:538-549
         if (!caches[l]) throw Error(PTTS_EINVAL, strfmt("native: voice model state module \"transformer.layers.%d.self_attn\" missing cache", l));
         if (offsets[l] < 0) throw Error(PTTS_EINVAL, strfmt("native: voice model state module \"transformer.layers.%d.self_attn\" has negative offset %lld", l, (long long)offsets[l]));
         if (offsets[l] > steps[l]) throw Error(PTTS_EINVAL, strfmt("native: voice model state module \"transformer.layers.%d.self_attn\" offset %lld exceeds cache length %lld", l, (long long)offsets[l], (long long)steps[l]));
         if (offsets[l] != offsets[0]) throw Error(PTTS_EINVAL, "ptts-hip: per-layer voice offsets differ; one offset per utterance is supported");
-        if (offsets[l] > b.cap) throw Error(PTTS_EINVAL, "ptts-hip: voice state longer than the KV capacity");
+        if (offsets[l] > cap) throw Error(PTTS_EINVAL, "ptts-hip: voice state longer than the KV capacity");
     }
+}
+
+Voice* voice_create(Model& m, const float* const* caches, const int64_t* steps, const int64_t* offsets) {
+    const Desc& d = m.d;
+    check_voice(d, caches, steps, offsets, ROPE_SEQ);
+    std::unique_ptr<Voice> v(new Voice());
+    v->m = &m;
+    v->offset = (int)offsets[0];
+    const size_t lb = v->layer_bytes();
+    v->k.ensure(std::max<size_t>(lb * d.n_layers, 256));
+    v->v.ensure(std::max<size_t>(lb * d.n_layers, 256));
+    for (int l = 0; l < d.n_layers; l++) {
+        size_t n = (size_t)2 * steps[l] * d.heads * d.hd;
+        DevBuf& raw = m.work(1, n * sizeof(float));
+        h2d(raw.p, caches[l], n * sizeof(float), m.stream);
+        launch_voice_scatter(raw.as<float>(), (int)steps[l], d.heads, d.hd, v->offset, 0, (char*)v->k.p + lb * l, (char*)v->v.p + lb * l,
+                             m.opts.kv == PTTS_KV_BF16, v->offset, m.stream);
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+    }
+    return v.release();
+}
+
+void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slots) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    if (v.m != &m) throw Error(PTTS_EINVAL, "ptts-hip: voice belongs to another model");
+    if (v.offset > b.cap) throw Error(PTTS_EINVAL, "ptts-hip: voice state longer than the KV capacity");
+    DevBuf& ds = m.work(10, slots.size() * sizeof(int32_t));
+    h2d(ds.p, slots.data(), slots.size() * sizeof(int32_t), m.stream);
+    const size_t lb = v.layer_bytes();
+    for (int l = 0; l < d.n_layers; l++)
+        launch_voice_apply((const char*)v.k.p + lb * l, (const char*)v.v.p + lb * l, v.offset, d.heads, d.hd, ds.as<int32_t>(), (int)slots.size(),
+                           b.kc(l), b.vc(l), (int)b.kv_elem(), b.cap, m.stream);
+    for (int32_t sl : slots) b.kv_len_host[sl] = v.offset;
+    h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)b.B * sizeof(int32_t), m.stream);
+}
+
+void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64_t* steps, const int64_t* offsets) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    if (slot < 0 || slot >= b.B) throw Error(PTTS_EINVAL, "ptts-hip: voice state slot out of range");
+    check_voice(d, caches, steps, offsets, b.cap);
     for (int l = 0; l < d.n_layers; l++) {
         size_t n = (size_t)2 * steps[l] * d.heads * d.hd;
         DevBuf& raw = m.work(1, n * sizeof(float));
@@ -274,6 +314,19 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
     h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)B * sizeof(int32_t), s);
 }
 
+// every linear of the AR step goes through here so that bench.py can time the dominant kernel with HIP events
+static void step_gemm(Model& m, const GemmArgs& g) {
+    Prof& p = m.prof;
+    if (!p.on) { launch_gemm(g, m.stream); return; }
+    while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
+    PTTS_HIP(hipEventRecord(p.ev[p.used], m.stream));
+    launch_gemm(g, m.stream);
+    PTTS_HIP(hipEventRecord(p.ev[p.used + 1], m.stream));
+    p.used += 2;
+    p.launches++;
+    p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 + (double)g.M * g.N * 4;
+}
+
 // FlowLM.SampleNextLatentStateful minus the host glue (flow_lm.go:252-288): input_linear, 6 x forwardWithState(Tq=1),
 // out_norm, out_eos, LSD decode through the flow net.  Everything reads device state, so the sequence is graph-capturable.
 void step_core(Batch& b, int lsd) {
@@ -287,11 +340,11 @@ void step_core(Batch& b, int lsd) {
     float* qkv = b.qkv.as<float>();
     float* attn = b.attn.as<float>();
     float* ff = b.ff.as<float>();
-    launch_gemm(mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B), s);
+    step_gemm(m, mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B));
     for (int l = 0; l < d.n_layers; l++) {
         const auto& L = d.layers[l];
         launch_layernorm(mkln(m, x, flat(D), L.n1, xn, D, B), s);
-        launch_gemm(mk(m, xn, flat(D), L.in_proj, qkv, flat(3 * D), B), s);
+        step_gemm(m, mk(m, xn, flat(D), L.in_proj, qkv, flat(3 * D), B));
         AttnArgs a;
         a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
         a.k_seg_stride = (int64_t)d.heads * b.cap * d.hd; a.k_head_stride = (int64_t)b.cap * d.hd; a.k_row_stride = d.hd;
@@ -304,18 +357,18 @@ void step_core(Batch& b, int lsd) {
         launch_attention(a, s);
         GemmArgs go = mk(m, attn, flat(D), L.out_proj, x, flat(D), B);
         go.R = x; go.epi = EPI_RESADD;
-        launch_gemm(go, s);
+        step_gemm(m, go);
         launch_layernorm(mkln(m, x, flat(D), L.n2, xn, D, B), s);
         GemmArgs g1 = mk(m, xn, flat(D), L.l1, ff, flat(d.ffn), B);
         g1.epi = EPI_GELU;
-        launch_gemm(g1, s);
+        step_gemm(m, g1);
         GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
         g2.R = x; g2.epi = EPI_RESADD;
-        launch_gemm(g2, s);
+        step_gemm(m, g2);
     }
     float* last = b.last.as<float>();
     launch_layernorm(mkln(m, x, flat(D), d.out_norm, last, D, B), s);
-    launch_gemm(mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B), s);
+    step_gemm(m, mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B));
     // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
     const float* tc = m.tcomb.at(lsd)->as<float>();
     float* sy = b.sy.as<float>();
@@ -327,9 +380,9 @@ void step_core(Batch& b, int lsd) {
     for (int i = 0; i < lsd; i++) {
         GemmArgs gc = mk(m, last, flat(D), d.cond_embed, sy, flat(C), B);  // sy = silu(0.5*(e_s+e_t) + cond_embed(c))
         gc.epi = EPI_SILU; gc.addvec = tc + (size_t)i * C;
-        launch_gemm(gc, s);
-        launch_gemm(mk(m, sy, flat(C), d.ada_all, ada, flat(NA), B), s);
-        launch_gemm(mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B), s);
+        step_gemm(m, gc);
+        step_gemm(m, mk(m, sy, flat(C), d.ada_all, ada, flat(NA), B));
+        step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
         for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
             const auto& rb = d.rb[r];
             LnArgs ln = mkln(m, fx, flat(C), rb.ln, fh, C, B);
@@ -337,10 +390,10 @@ void step_core(Batch& b, int lsd) {
             launch_layernorm(ln, s);
             GemmArgs g0 = mk(m, fh, flat(C), rb.mlp0, fh2, flat(C), B);
             g0.epi = EPI_SILU;
-            launch_gemm(g0, s);
+            step_gemm(m, g0);
             GemmArgs g2 = mk(m, fh2, flat(C), rb.mlp2, fx, flat(C), B);
             g2.R = fx; g2.epi = EPI_GATE_RESADD; g2.gate = ada + (size_t)r * 3 * C + 2 * C; g2.ldg = NA;
-            launch_gemm(g2, s);
+            step_gemm(m, g2);
         }
         LnArgs lf;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
         lf.x = fx; lf.xmap = flat(C); lf.eps = 1e-6f; lf.y = fh; lf.ldy = C; lf.rows = B; lf.d = C;
@@ -348,7 +401,7 @@ void step_core(Batch& b, int lsd) {
         launch_layernorm(lf, s);
         GemmArgs gf = mk(m, fh, flat(C), d.final_linear, cur, flat(d.ldim), B);  // current += flow * (1/steps)
         gf.R = cur; gf.epi = EPI_AXPY; gf.alpha = 1.0f / (float)lsd;
-        launch_gemm(gf, s);
+        step_gemm(m, gf);
     }
 }
 
@@ -530,7 +583,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         const ptts_request& r = reqs[idx[i]];
         ms[i] = resolve_max_steps(r);
         tp[i] = (int)r.n_tokens + (r.voice_embedding ? (int)r.voice_frames : 0);
-        off[i] = r.voice_caches ? (int)r.voice_offsets[0] : 0;
+        off[i] = r.voice ? reinterpret_cast<const Voice*>(r.voice)->offset : (r.voice_caches ? (int)r.voice_offsets[0] : 0);
         cap_need = std::max(cap_need, off[i] + tp[i] + ms[i]);
         ms_max = std::max(ms_max, ms[i]);
     }
@@ -550,9 +603,14 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         h2d(b.st.frames_after_eos, v_fae.data(), (size_t)B * 4, s);
         h2d(b.st.eos_threshold, v_thr.data(), (size_t)B * 4, s);
     }
-    for (int i = 0; i < B; i++) {
-        const ptts_request& r = reqs[idx[i]];
-        if (r.voice_caches) batch_set_voice(b, i, r.voice_caches, r.voice_cache_steps, r.voice_offsets);
+    {
+        std::map<const Voice*, std::vector<int32_t>> by_voice;
+        for (int i = 0; i < B; i++) {
+            const ptts_request& r = reqs[idx[i]];
+            if (r.voice) by_voice[reinterpret_cast<const Voice*>(r.voice)].push_back(i);
+            else if (r.voice_caches) batch_set_voice(b, i, r.voice_caches, r.voice_cache_steps, r.voice_offsets);
+        }
+        for (auto& kv : by_voice) batch_apply_voice(b, *kv.first, kv.second);
     }
     // text (+ voice) embeddings packed as rows (runtime_native_safetensors.go:89-119)
     std::vector<int64_t> row_off((size_t)B + 1, 0);
@@ -587,7 +645,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             if (reqs[idx[i]].noise) h2d(b.noise.as<float>() + (size_t)i * b.max_steps * ld, reqs[idx[i]].noise, (size_t)ms[i] * ld * sizeof(float), s);
     }
     m.tcomb_for(lsd);
-    const bool use_graph = m.opts.use_graph != 0;
+    const bool use_graph = m.opts.use_graph != 0 && !m.prof.on;
     if (use_graph) capture_step_graph(b, lsd);
     bool may_stop = false, any_cb = false;
     for (int i = 0; i < B; i++) {
@@ -667,7 +725,7 @@ void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res) {
         const ptts_request& q = reqs[i];
         std::string err;
         if (!q.tokens || q.n_tokens <= 0) err = "generate: token slice must not be empty";
-        else if (q.voice_embedding && q.voice_caches) err = "generate: voice embedding and voice model state are mutually exclusive";
+        else if ((q.voice_embedding != nullptr) + (q.voice_caches != nullptr) + (q.voice != nullptr) > 1) err = "generate: voice embedding and voice model state are mutually exclusive";
         else if (q.voice_caches && (!q.voice_cache_steps || !q.voice_offsets)) err = "generate: load voice model state: missing cache steps/offsets";
         else {
             for (int64_t t = 0; t < q.n_tokens; t++)

@@ -31,6 +31,14 @@ struct DevBuf {
 
 struct Batch;
 
+struct Prof {   // bench.py measurement hook (ptts_profile_*)
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double bytes = 0;
+    int64_t launches = 0;
+};
+
 struct Model {
     Desc d;
     ptts_opts opts;
@@ -42,6 +50,7 @@ struct Model {
     std::map<int, std::unique_ptr<DevBuf>> tcomb;  // lsd_steps -> [n][flow_dim]: 0.5*(embed_s(i/n) + embed_t((i+1)/n))
     std::vector<std::unique_ptr<DevBuf>> ws;       // grow-only workspaces (Mimi decode, prefill)
     std::unique_ptr<Batch> cached_batch;
+    Prof prof;
 
     ~Model();
     template <class T> const T* at(size_t off) const { return off == NONE ? nullptr : reinterpret_cast<const T*>(arena + off); }
@@ -81,6 +90,16 @@ struct Batch {
     void* kc(int layer) const { return (char*)kcache.p + (size_t)layer * B * m->d.heads * cap * m->d.hd * kv_elem(); }
     void* vc(int layer) const { return (char*)vcache.p + (size_t)layer * B * m->d.heads * cap * m->d.hd * kv_elem(); }
 };
+
+// a voice model state resident in HBM: K and V per layer as [H][offset][hd] in the cache dtype
+struct Voice {
+    Model* m = nullptr;
+    int offset = 0;
+    DevBuf k, v;
+    size_t layer_bytes() const { return (size_t)m->d.heads * offset * m->d.hd * (m->opts.kv == PTTS_KV_BF16 ? 2 : 4); }
+};
+Voice* voice_create(Model& m, const float* const* caches, const int64_t* steps, const int64_t* offsets);
+void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slots);
 
 Model* model_open(Plan* plan, void* device_arena, int fill);
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);

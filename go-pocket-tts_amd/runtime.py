@@ -59,7 +59,11 @@ class _Request(C.Structure):
                 ("frames_after_eos", C.c_int32), ("voice_embedding", _FP), ("voice_frames", C.c_int64),
                 ("voice_caches", C.POINTER(_FP)), ("voice_cache_steps", _IP), ("voice_offsets", _IP), ("noise", _FP),
                 ("step_callback", _STEP_CB), ("callback_user", C.c_void_p), ("cancel", C.POINTER(C.c_int32)),
-                ("want_latents", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("want_latents", C.c_int32), ("reserved0", C.c_int32), ("voice", C.c_void_p), ("reserved", C.c_int32 * 4)]
+
+
+class _Profile(C.Structure):
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double), ("kernel", C.c_char * 64)]
 
 
 class _Result(C.Structure):
@@ -77,6 +81,7 @@ ABI_SYMBOLS = [
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
     "ptts_decode_latents", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
+    "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read",
 ]
 
 
@@ -129,6 +134,10 @@ def lib():
         L.ptts_batch_read_kv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, _FP]
         L.ptts_decode_latents.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP]
         L.ptts_flow_direction.argtypes = [C.c_void_p, _FP, C.c_float, C.c_float, _FP, C.c_int32, _FP]
+        L.ptts_voice_create.argtypes = [C.c_void_p, C.POINTER(_FP), _IP, _IP, C.POINTER(C.c_void_p)]
+        L.ptts_voice_free.argtypes = [C.c_void_p]
+        L.ptts_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+        L.ptts_profile_read.argtypes = [C.c_void_p, C.POINTER(_Profile)]
         L.ptts_op_linear.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int64, C.c_int64, _FP]
         L.ptts_op_layernorm.argtypes = [_FP, _FP, _FP, C.c_float, C.c_int64, C.c_int64, _FP]
         L.ptts_op_rope.argtypes = [_FP, _FP, _FP] + [C.c_int64] * 5
@@ -186,6 +195,7 @@ class RuntimeGenerateConfig:
     mimi_sequence_length: int = 0
     voice_embedding: Optional[VoiceEmbedding] = None
     voice_model_state: Optional[VoiceModelState] = None
+    device_voice: Optional["DeviceVoice"] = None   # a VoiceModelState already uploaded with Model.upload_voice
     step_callback: Optional[Callable[[int, int], None]] = None
     noise: Optional[np.ndarray] = None
     cancel: Optional[np.ndarray] = None  # int32[1]; nonzero = cancelled (the ctx of GenerateAudio)
@@ -275,6 +285,22 @@ class Model:
         _check(lib().ptts_text_embeddings(self.h, _ip(ids), ids.size, _fp(out)))
         return out
 
+    def upload_voice(self, state: VoiceModelState) -> "DeviceVoice":
+        """Keeps a voice model state in HBM (the reference re-reads the file per Synthesize call: service.go:127,216-246)."""
+        ptrs, steps, offs, arrs = _voice_arrays(state, self.info.n_layers)
+        h = C.c_void_p()
+        _check(lib().ptts_voice_create(self.h, ptrs, _ip(steps), _ip(offs), C.byref(h)))
+        return DeviceVoice(h.value, int(offs[0]))
+
+    def profile_enable(self, on: bool):
+        _check(lib().ptts_profile_enable(self.h, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        p = _Profile()
+        _check(lib().ptts_profile_read(self.h, C.byref(p)))
+        return {"kernel": p.kernel.decode(), "launches": int(p.launches), "total_ms": float(p.total_ms),
+                "algorithmic_bytes": float(p.algorithmic_bytes)}
+
     def new_batch(self, n_slots: int, kv_capacity: int) -> "Batch":
         return Batch(self, n_slots, kv_capacity)
 
@@ -318,6 +344,8 @@ class Model:
                 ptrs, steps, offs, arrs = _voice_arrays(cfg.voice_model_state, self.info.n_layers)
                 keep += [ptrs, steps, offs, arrs]
                 r.voice_caches, r.voice_cache_steps, r.voice_offsets = ptrs, _ip(steps), _ip(offs)
+            if cfg.device_voice is not None:
+                r.voice = cfg.device_voice.h
             if cfg.noise is not None:
                 nz = _f32(cfg.noise).reshape(-1, self.info.ldim)
                 keep.append(nz)
@@ -344,6 +372,24 @@ class Model:
             for i in range(n):
                 lib().ptts_free_result(C.byref(ress[i]))
         return out
+
+
+class DeviceVoice:
+    def __init__(self, handle: int, offset: int):
+        self.h, self.offset = handle, offset
+
+    def close(self):
+        if self.h:
+            lib().ptts_voice_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        if sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
 
 
 def _voice_arrays(state: VoiceModelState, n_layers: int):

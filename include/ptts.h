@@ -48,6 +48,7 @@ extern "C" {
 typedef struct ptts_model ptts_model;
 typedef struct ptts_plan  ptts_plan;
 typedef struct ptts_batch ptts_batch;
+typedef struct ptts_voice ptts_voice;
 
 typedef struct ptts_opts {
     int32_t device;          /* HIP device ordinal */
@@ -110,7 +111,12 @@ typedef struct ptts_request {
     ptts_step_callback step_callback; void* callback_user;
     const volatile int32_t* cancel;                   /* polled between steps; nonzero -> PTTS_ECANCELLED */
     int32_t want_latents;                             /* 1: also return the latent frames */
-    int32_t reserved[7];
+    int32_t reserved0;
+    /* a voice model state already resident in HBM (ptts_voice_create); exclusive with the two host forms above.
+     * The reference loads the voice file once per Synthesize call and rebuilds the FlowLM state from it for
+     * every chunk (service.go:127,216-246, flow_lm.go:134-145); the device copy is that cached voice. */
+    const ptts_voice* voice;
+    int32_t reserved[4];
 } ptts_request;
 
 typedef struct ptts_result {
@@ -125,6 +131,22 @@ typedef struct ptts_result {
  * extension: independent utterance chunks stepped together (per-row EOS countdown, ragged KV). */
 int  ptts_generate(ptts_model* m, const ptts_request* reqs, int32_t n_reqs, ptts_result* results);
 void ptts_free_result(ptts_result* r);
+
+/* Uploads a voice model state ([2,1,T,H,Dh] f32 per layer + offsets; safetensors.LoadVoiceModelState,
+ * reader.go:127-140,273-308) once; requests then reference it by handle. */
+int  ptts_voice_create(ptts_model* m, const float* const* caches, const int64_t* cache_steps, const int64_t* offsets, ptts_voice** out);
+void ptts_voice_free(ptts_voice* v);
+
+/* Measurement hook for bench.py: while enabled the AR step runs eagerly (no graph) with a HIP event pair around
+ * every launch of the dominant (weight-streaming linear) kernel on the model's stream. */
+typedef struct ptts_profile {
+    int64_t launches;
+    double  total_ms;            /* sum of the event-pair durations */
+    double  algorithmic_bytes;   /* sum over launches of weights + activations in + out */
+    char    kernel[64];
+} ptts_profile;
+int ptts_profile_enable(ptts_model* m, int32_t on);
+int ptts_profile_read(ptts_model* m, ptts_profile* out);   /* returns and resets the counters */
 
 /* ---- staged entry points = the native.Model methods GenerateAudio calls (model.go:76-138,141,410).
  *      A ptts_batch is n_slots independent FlowLMState objects (flow_lm.go:45-49) held in HBM. ---- */

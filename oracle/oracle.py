@@ -200,7 +200,8 @@ def lib():
         L.po_dot.restype = C.c_float
         L.po_dot_generic.restype = C.c_float
         L.po_dot_avx2_order.restype = C.c_float
-        for f in ("po_dot", "po_dot_generic", "po_dot_avx2_order"):
+        L.po_dot_avx2_emul.restype = C.c_float
+        for f in ("po_dot", "po_dot_generic", "po_dot_avx2_order", "po_dot_avx2_emul"):
             getattr(L, f).argtypes = [_FP, _FP, C.c_int64]
         L.po_model_create.restype = C.c_void_p
         L.po_model_create.argtypes = [C.POINTER(_PoTensor), C.c_int32, C.c_char_p, C.c_int32]
@@ -247,7 +248,8 @@ def set_use_avx2(on: bool) -> None:
 
 def dot(a, b, mode: str = "auto") -> float:
     a, b = _f32(a), _f32(b)
-    fn = {"auto": lib().po_dot, "generic": lib().po_dot_generic, "avx2": lib().po_dot_avx2_order}[mode]
+    fn = {"auto": lib().po_dot, "generic": lib().po_dot_generic, "avx2": lib().po_dot_avx2_order,
+          "avx2_emul": lib().po_dot_avx2_emul}[mode]
     return float(fn(_fp(a), _fp(b), C.c_int64(a.size)))
 
 

@@ -32,7 +32,8 @@ void po_set_use_avx2(int on);
 /* ---- leaf primitives (runtime/tensor) ---- */
 float po_dot(const float* a, const float* b, int64_t n);               /* dot.go:42, dot_amd64.go:13 */
 float po_dot_generic(const float* a, const float* b, int64_t n);       /* dot.go:11-39 */
-float po_dot_avx2_order(const float* a, const float* b, int64_t n);    /* dot_amd64.s:34-116 (scalar emulation) */
+float po_dot_avx2_order(const float* a, const float* b, int64_t n);    /* dot_amd64.s:34-116 (AVX2+FMA intrinsics when built with -mavx2 -mfma) */
+float po_dot_avx2_emul(const float* a, const float* b, int64_t n);     /* the same order, scalar fmaf per lane */
 void  po_axpy(float* dst, int64_t ndst, float alpha, const float* src, int64_t nsrc); /* axpy.go:5-13 */
 int   po_softmax_lastdim(const float* x, int64_t outer, int64_t d, float* y);  /* nn_ops.go:15-76 */
 int   po_layernorm(const float* x, const float* w, const float* b, float eps,

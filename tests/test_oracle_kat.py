@@ -50,6 +50,7 @@ def test_dot_orders_agree_and_avx2_emulation_matches_intrinsics_shape():
         ref = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
         assert abs(O.dot(a, b, "avx2") - ref) < 1e-3 * max(1.0, abs(ref))
         assert abs(O.dot(a, b, "generic") - ref) < 1e-3 * max(1.0, abs(ref))
+        assert O.dot(a, b, "avx2") == O.dot(a, b, "avx2_emul")   # intrinsics and lane-by-lane restatement: same bits
     # n < 8 takes the generic path even with AVX2 on (dot_amd64.go:13-19)
     a, b = rng.standard_normal(7).astype(np.float32), rng.standard_normal(7).astype(np.float32)
     assert O.dot(a, b, "auto") == O.dot(a, b, "generic")
