@@ -218,7 +218,7 @@ int ptts_profile_read(ptts_model* h, ptts_profile* out) {
         out->launches = m.prof.launches;
         out->total_ms = ms;
         out->algorithmic_bytes = m.prof.bytes;
-        snprintf(out->kernel, sizeof out->kernel, "%s", "k_gemm");
+        snprintf(out->kernel, sizeof out->kernel, "%s", "k_skinny");
         m.prof.used = 0; m.prof.bytes = 0; m.prof.launches = 0;
     });
 }
@@ -448,6 +448,37 @@ int ptts_flow_direction(ptts_model* h, const float* c, float sv, float tv, const
 }
 
 // ---- kernel-level entry points ----
+
+// timing aid (tools/microbench.py): `iters` back-to-back launches of the step linear on random operands
+int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, int32_t iters, float* avg_us) {
+    return guard([&] {
+        require_device();
+        Tmp dA((size_t)M * K * 4), dW((size_t)N * K * 4), dC((size_t)M * N * 4 * (splitk > 1 ? splitk : 1)), dlnw((size_t)K * 4);
+        PTTS_HIP(hipMemset(dA.p, 0x3c, (size_t)M * K * 4));
+        PTTS_HIP(hipMemset(dW.p, 0x3c, (size_t)N * K * (w_bf16 ? 2 : 4)));
+        PTTS_HIP(hipMemset(dlnw.p, 0x3c, (size_t)K * 4));
+        GemmArgs g;
+        g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
+        g.W = dW.p; g.w_bf16 = w_bf16; g.ldw = K;
+        g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
+        g.M = M; g.N = N; g.K = K;
+        SkinnyFuse fu;
+        if (fuse_ln) { fu.ln = 1; fu.ln_w = dlnw.as<float>(); fu.ln_b = dlnw.as<float>(); }
+        if (!(fuse_ln ? skinny_fuse_supported(g, fu) : skinny_supported(g, splitk))) throw Error(PTTS_EINVAL, "shape not supported");
+        hipEvent_t e0, e1;
+        PTTS_HIP(hipEventCreate(&e0)); PTTS_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 5; i++) launch_skinny(g, fu, splitk, dC.as<float>(), nullptr);
+        PTTS_HIP(hipDeviceSynchronize());
+        PTTS_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; i++) launch_skinny(g, fu, splitk, dC.as<float>(), nullptr);
+        PTTS_HIP(hipEventRecord(e1, nullptr));
+        PTTS_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        PTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = ms * 1e3f / (float)iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    });
+}
 
 int ptts_op_linear(const float* x, const float* w, const float* bias, int64_t rows, int64_t in, int64_t out, float* y) {
     return guard([&] {

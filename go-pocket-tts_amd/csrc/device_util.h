@@ -1,0 +1,42 @@
+// device_util.h -- small device/host helpers shared by the .hip files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+
+#include "kernels.h"
+
+namespace ptts {
+
+#define WAVE 64
+
+__device__ __forceinline__ int64_t row_off(const RowMap& m, int64_t r) {
+    return m.rows_per_batch ? (r / m.rows_per_batch) * m.batch_stride + (r % m.rows_per_batch) * m.ld : r * m.ld;
+}
+
+__device__ __forceinline__ float elu1(float v) { return v <= 0.0f ? expf(v) - 1.0f : v; }        // tensor_util.go:119-128
+__device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }                  // tensor_util.go:73-82
+__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // :84-94
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace ptts

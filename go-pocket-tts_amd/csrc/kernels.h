@@ -33,6 +33,7 @@ struct GemmArgs {
     // C[M, N] = epi( aop(A)[M, K] * W[N, K]^T )
     const float* A = nullptr; RowMap amap;
     const void*  W = nullptr; int w_bf16 = 0; int64_t ldw = 0;
+    const void*  Wt = nullptr;       // fragment-ordered copy of W for the AR-step kernel (model.cpp add_tiled), optional
     const float* bias = nullptr;     // [N] or null
     const float* addvec = nullptr;   // [N] or null (EPI_SILU only)
     float*       C = nullptr; RowMap cmap;
@@ -43,7 +44,27 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
 };
-void launch_gemm(const GemmArgs& a, hipStream_t stream);
+void launch_gemm(const GemmArgs& a, hipStream_t stream);   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
+bool gemm2_supported(const GemmArgs& a);
+void launch_gemm2(const GemmArgs& a, hipStream_t stream);
+
+// Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
+// splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.
+// The optional prologue (SkinnyFuse; needs K == row width <= 1024, splitk == 1) folds the preceding residual update
+// and LayerNorm into the activation staging.
+struct SkinnyFuse {
+    // x[row] += pgate[row] * (sum_z partial[z][row] + pbias)   (partial: [psplit][M][K])
+    const float* partial = nullptr; int psplit = 0; int64_t pstride = 0;
+    const float* pbias = nullptr; const float* pgate = nullptr; int64_t ldpg = 0;
+    float* x_out = nullptr;          // the updated rows, written once (dense [M, K]); must not alias A
+    int ln = 0;                      // 1: LayerNorm the rows before the product
+    const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+    const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;   // adaLN modulation
+    float* y_out = nullptr;          // the normalised rows, written once (dense [M, K])
+};
+bool skinny_supported(const GemmArgs& a, int splitk);
+bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
+void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream);
 
 struct LnArgs {
     const float* x = nullptr; RowMap xmap;
@@ -51,8 +72,13 @@ struct LnArgs {
     float eps = 1e-5f;
     // optional adaLN modulation y = y * (1 + scale[row]) + shift[row]   (tensor_util.go:175-193)
     const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;
-    float* y = nullptr; int64_t ldy = 0;
+    float* y = nullptr; int64_t ldy = 0;   // y == null: reduction prologue only
     int rows = 0, d = 0;
+    // optional fused split-K reduction + residual update, applied before the normalisation (flat rows, d % 4 == 0):
+    //   x[row] += pgate[row] * pscale * (sum_z partial[z][row] + pbias)       (x is updated in place)
+    const float* partial = nullptr; int splitk = 0; int64_t pstride = 0;
+    const float* pbias = nullptr; const float* pgate = nullptr; int64_t ldpg = 0;
+    const float* pscale = nullptr;
 };
 void launch_layernorm(const LnArgs& a, hipStream_t stream);
 // Bessel-variance "RMS" norm of the timestep embedder (tensor_util.go:273-326), in place

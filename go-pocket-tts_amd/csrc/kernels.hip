@@ -5,38 +5,9 @@
 // Mimi decoder, so that a causal convolution window is one contiguous span and every
 // global access is a coalesced 16-byte-per-lane stream); weights are [out, in] row-major.
 #include "kernels.h"
-
-#include <cmath>
+#include "device_util.h"
 
 namespace ptts {
-
-#define WAVE 64
-
-__device__ __forceinline__ int64_t row_off(const RowMap& m, int64_t r) {
-    return m.rows_per_batch ? (r / m.rows_per_batch) * m.batch_stride + (r % m.rows_per_batch) * m.ld : r * m.ld;
-}
-
-__device__ __forceinline__ float elu1(float v) { return v <= 0.0f ? expf(v) - 1.0f : v; }        // tensor_util.go:119-128
-__device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }                  // tensor_util.go:73-82
-__device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // :84-94
-
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-}
-
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // GEMM  C[M,N] = epi( aop(A)[M,K] * W[N,K]^T )       (K4, K8, K11, K13-K17: every Linear / Conv1d /
@@ -169,66 +140,14 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
     }
 }
 
-static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
-
 void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return;
+    if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;
     int w_vec = a.w_bf16 ? ((reinterpret_cast<uintptr_t>(a.W) & 7) == 0 && a.ldw % 4 == 0) : (aligned16(a.W) && a.ldw % 4 == 0);
     dim3 grid((a.N + GN - 1) / GN, (a.M + GM - 1) / GM);
     if (a.w_bf16) hipLaunchKernelGGL(k_gemm<true>, grid, dim3(256), 0, stream, a, a_vec, w_vec);
     else hipLaunchKernelGGL(k_gemm<false>, grid, dim3(256), 0, stream, a, a_vec, w_vec);
-}
-
-// ------------------------------------------------------------------------------------------------
-// LayerNorm (K3; linear.go:265-329 / nn_ops.go:79-149): one wave per row, mean and biased variance
-// accumulated in f64 exactly as the reference does, optional adaLN modulation fused (K11).
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_layernorm(LnArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= a.rows) return;
-    const float* x = a.x + row_off(a.xmap, row);
-    double s = 0.0;
-    for (int i = lane; i < a.d; i += WAVE) s += (double)x[i];
-    const double mean = wave_sum(s) / (double)a.d;
-    double v = 0.0;
-    for (int i = lane; i < a.d; i += WAVE) { double dlt = (double)x[i] - mean; v += dlt * dlt; }
-    const double var = wave_sum(v) / (double)a.d;
-    const float inv_std = (float)(1.0 / sqrt(var + (double)a.eps));
-    const float meanf = (float)mean;
-    float* y = a.y + (int64_t)row * a.ldy;
-    const float* sh = a.shift ? a.shift + (int64_t)row * a.ldmod : nullptr;
-    const float* sc = a.scale ? a.scale + (int64_t)row * a.ldmod : nullptr;
-    for (int i = lane; i < a.d; i += WAVE) {
-        float n = (x[i] - meanf) * inv_std;
-        if (a.w) n = n * a.w[i];
-        if (a.b) n = n + a.b[i];
-        if (sc) n = n * (sc[i] + 1.0f) + sh[i];
-        y[i] = n;
-    }
-}
-void launch_layernorm(const LnArgs& a, hipStream_t stream) {
-    if (a.rows <= 0) return;
-    hipLaunchKernelGGL(k_layernorm, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
-}
-
-__global__ __launch_bounds__(64) void k_rmsnorm_alpha(float* x, const float* alpha, float eps, int rows, int d) {
-    // tensor_util.go:273-326: unbiased variance about the mean, x itself is NOT centred
-    const int lane = threadIdx.x, row = blockIdx.x;
-    float* r = x + (int64_t)row * d;
-    double s = 0.0;
-    for (int i = lane; i < d; i += WAVE) s += (double)r[i];
-    const double mean = wave_sum(s) / (double)d;
-    double v = 0.0;
-    for (int i = lane; i < d; i += WAVE) { double dlt = (double)r[i] - mean; v += dlt * dlt; }
-    double var = wave_sum(v);
-    if (d > 1) var /= (double)(d - 1);
-    const float inv = (float)(1.0 / sqrt(var + (double)eps));
-    for (int i = lane; i < d; i += WAVE) r[i] = r[i] * inv * alpha[i];
-}
-void launch_rmsnorm_alpha(float* x, const float* alpha, float eps, int rows, int d, hipStream_t stream) {
-    hipLaunchKernelGGL(k_rmsnorm_alpha, dim3(rows), dim3(64), 0, stream, x, alpha, eps, rows, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -454,19 +373,24 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     }
     const float scale = 0.125f;  // 1/sqrt(64)
 
-    // pass 1: scores
-    for (int base = wq * 4; base < nk; base += WPQ * 4) {
-        int jj = base + kq;
-        float p = 0.0f;
-        if (jj < nk) {
-            float4 k4 = load_kv4<KVBF16>(kbase, (int64_t)(j0 + jj) * a.k_row_stride + sub * 4);
-            p = q4.x * k4.x + q4.y * k4.y + q4.z * k4.z + q4.w * k4.w;
+    // pass 1: scores.  16 keys per wave-iteration: the four 1-KiB key loads are issued before any is consumed
+    for (int base = wq * 16; base < nk; base += WPQ * 16) {
+        float4 k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int jj = base + u * 4 + kq;
+            k4[u] = jj < nk ? load_kv4<KVBF16>(kbase, (int64_t)(j0 + jj) * a.k_row_stride + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        p += __shfl_xor(p, 8, WAVE);
-        p += __shfl_xor(p, 4, WAVE);
-        p += __shfl_xor(p, 2, WAVE);
-        p += __shfl_xor(p, 1, WAVE);
-        if (sub == 0 && jj < nk) sc[jj] = p * scale;
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int jj = base + u * 4 + kq;
+            float p = q4.x * k4[u].x + q4.y * k4[u].y + q4.z * k4[u].z + q4.w * k4[u].w;
+            p += __shfl_xor(p, 8, WAVE);
+            p += __shfl_xor(p, 4, WAVE);
+            p += __shfl_xor(p, 2, WAVE);
+            p += __shfl_xor(p, 1, WAVE);
+            if (sub == 0 && jj < nk) sc[jj] = p * scale;
+        }
     }
     __syncthreads();
     // softmax statistics (every wave of the query computes the same values)
@@ -476,14 +400,22 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     float sum = 0.0f;
     for (int j = lane; j < nk; j += WAVE) sum += expf(sc[j] - mx);
     sum = wave_sum(sum);
-    // pass 2: P * V
+    // pass 2: P * V, same 16-keys-in-flight shape
     float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int base = wq * 4; base < nk; base += WPQ * 4) {
-        int jj = base + kq;
-        if (jj < nk) {
-            float p = expf(sc[jj] - mx);
-            float4 v4 = load_kv4<KVBF16>(vbase, (int64_t)(j0 + jj) * a.k_row_stride + sub * 4);
-            o.x += p * v4.x; o.y += p * v4.y; o.z += p * v4.z; o.w += p * v4.w;
+    for (int base = wq * 16; base < nk; base += WPQ * 16) {
+        float4 v4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int jj = base + u * 4 + kq;
+            v4[u] = jj < nk ? load_kv4<KVBF16>(vbase, (int64_t)(j0 + jj) * a.k_row_stride + sub * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            int jj = base + u * 4 + kq;
+            if (jj < nk) {
+                float p = expf(sc[jj] - mx);
+                o.x += p * v4[u].x; o.y += p * v4[u].y; o.z += p * v4[u].z; o.w += p * v4[u].w;
+            }
         }
     }
 #pragma unroll
@@ -626,25 +558,43 @@ void launch_voice_apply(const void* vk, const void* vv, int offset, int heads, i
                        heads, row16, slots, n_slots, (uint4*)kcache, (uint4*)vcache, cap);
 }
 
-// K16 (last layer): ELU then causal conv C -> 1 (mimi.go:781-783); window of k rows is one contiguous span
-__global__ void k_conv_final(const float* in, int pad, const float* w, const float* bias, int b, int t, int c, int k, float* out) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (int64_t)b * t) return;
-    int tt = (int)(i % t), bi = (int)(i / t);
-    const float* x = in + ((int64_t)bi * (pad + t) + pad + tt - (k - 1)) * c;
-    float s = 0.0f;
-    int n = k * c;
-    for (int j = 0; j < n; j += 4) {
-        float4 v = *reinterpret_cast<const float4*>(x + j);
-        float4 ww = *reinterpret_cast<const float4*>(w + j);
-        s += elu1(v.x) * ww.x + elu1(v.y) * ww.y + elu1(v.z) * ww.z + elu1(v.w) * ww.w;
+// K16 (last layer): ELU then causal conv C -> 1 (mimi.go:781-783).  A block produces 256 consecutive samples of one
+// utterance: the (256 + k - 1) x C input window is one contiguous span in the channels-last buffer, staged into LDS with
+// coalesced 16-byte loads (ELU applied on the way); each thread then reduces its k*C window from LDS.  Rows are padded
+// by one float so that the 64 lanes (64 consecutive rows) read 64 different banks.
+__global__ __launch_bounds__(256) void k_conv_final(const float* in, int pad, const float* w, const float* bias, int b, int t, int c,
+                                                    int k, float* out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [(256 + k - 1)][c + 1], then w[k * c]
+    const int tiles_per_b = (t + 255) / 256;
+    const int bi = blockIdx.x / tiles_per_b, t0 = (blockIdx.x % tiles_per_b) * 256;
+    const int rows = min(256, t - t0) + k - 1;
+    const int ld = c + 1;
+    float* wl = tile + (256 + k - 1) * ld;
+    const float* src = in + ((int64_t)bi * (pad + t) + pad + t0 - (k - 1)) * c;
+    const int nv = rows * c / 4;
+    for (int i = threadIdx.x; i < nv; i += 256) {
+        float4 v = reinterpret_cast<const float4*>(src)[i];
+        int r = (i * 4) / c, col = (i * 4) % c;
+        float* d = tile + r * ld + col;
+        d[0] = elu1(v.x); d[1] = elu1(v.y); d[2] = elu1(v.z); d[3] = elu1(v.w);
     }
-    out[i] = s + (bias ? bias[0] : 0.0f);
+    for (int i = threadIdx.x; i < k * c; i += 256) wl[i] = w[i];
+    __syncthreads();
+    const int tt = t0 + threadIdx.x;
+    if (tt >= t) return;
+    float s = 0.0f;
+    for (int x = 0; x < k; x++) {
+        const float* row = tile + (threadIdx.x + x) * ld;
+        const float* wr = wl + x * c;
+        for (int j = 0; j < c; j++) s += row[j] * wr[j];
+    }
+    out[(int64_t)bi * t + tt] = s + (bias ? bias[0] : 0.0f);
 }
 void launch_conv_final(const float* in, int in_pad_rows, const float* w, const float* bias, int b, int t, int c, int k,
                        float* out, hipStream_t stream) {
-    int64_t tot = (int64_t)b * t;
-    hipLaunchKernelGGL(k_conv_final, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, in_pad_rows, w, bias, b, t, c, k, out);
+    const int tiles = (t + 255) / 256;
+    size_t lds = ((size_t)(256 + k - 1) * (c + 1) + (size_t)k * c) * sizeof(float);
+    hipLaunchKernelGGL(k_conv_final, dim3((unsigned)(b * tiles)), dim3(256), lds, stream, in, in_pad_rows, w, bias, b, t, c, k, out);
 }
 
 __global__ void k_zero_rows(float* base, int64_t batch_stride, int b, int64_t n) {

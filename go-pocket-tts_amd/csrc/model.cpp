@@ -55,6 +55,37 @@ struct Walker {
         if (shape(n).size() != rank) throw Error(PTTS_EFORMAT, strfmt("native: tensor \"%s\" rank %zu, want %zu", n.c_str(), shape(n).size(), rank));
     }
 
+    // Fragment-ordered copy for the AR-step kernel: per (16-row tile, 128-deep super-step) one block of WV KiB in which
+    // MFMA step s of lane l reads 16 contiguous bytes at [s][l]: W[tile*16 + (l & 15)][ss*128 + (l >> 4)*32 + s*E .. +E),
+    // E = 8 (bf16) or 4 (f32).  Every wave-level weight load of the step is then one contiguous 1-KiB burst.
+    void add_tiled(Lin& l, const std::function<void(float*)>& fill_rowmajor) {
+        const int E = bf16w ? 8 : 4, WV = bf16w ? 4 : 8;
+        const size_t nt = ((size_t)l.out + 15) / 16, nss = ((size_t)l.in + 127) / 128;
+        const size_t count = nt * nss * 16 * 128;
+        l.wt = reserve(count * (bf16w ? 2 : 4));
+        if (!host) return;
+        std::vector<float> rm((size_t)l.out * l.in);
+        fill_rowmajor(rm.data());
+        uint8_t* dst = host + l.wt;
+        for (size_t t = 0; t < nt; t++)
+            for (size_t ss = 0; ss < nss; ss++)
+                for (int sidx = 0; sidx < WV; sidx++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < E; j++) {
+                            size_t n = t * 16 + (size_t)(lane & 15), k = ss * 128 + (size_t)(lane >> 4) * 32 + (size_t)sidx * E + j;
+                            float v = (n < (size_t)l.out && k < (size_t)l.in) ? rm[n * l.in + k] : 0.0f;
+                            size_t e = ((((t * nss + ss) * WV + sidx) * 64 + lane) * E + j);
+                            if (bf16w) reinterpret_cast<uint16_t*>(dst)[e] = f32_to_bf16_rne(v);
+                            else reinterpret_cast<float*>(dst)[e] = v;
+                        }
+    }
+    Lin step_linear(const std::string& name, bool with_bias) {
+        Lin l = linear(name, with_bias);
+        const std::string wn = name + ".weight";
+        add_tiled(l, [&](float* dst) { f.decode_f32(wn, dst); });
+        return l;
+    }
+
     Lin linear(const std::string& name, bool with_bias) {  // linear.go:18-45
         Lin l;
         const std::string wn = name + ".weight";
@@ -166,10 +197,10 @@ struct Walker {
             auto& L = d.layers[i];
             L.n1 = norm(p + ".norm1", 1e-5f);
             L.n2 = norm(p + ".norm2", 1e-5f);
-            L.in_proj = linear(p + ".self_attn.in_proj", false);
-            L.out_proj = linear(p + ".self_attn.out_proj", false);
-            L.l1 = linear(p + ".linear1", false);
-            L.l2 = linear(p + ".linear2", false);
+            L.in_proj = step_linear(p + ".self_attn.in_proj", false);
+            L.out_proj = step_linear(p + ".self_attn.out_proj", false);
+            L.l1 = step_linear(p + ".linear1", false);
+            L.l2 = step_linear(p + ".linear2", false);
             if (L.out_proj.out % d.heads) throw Error(PTTS_EFORMAT, strfmt("native: d_model %d not divisible by num_heads %d", L.out_proj.out, d.heads));
             d.n_layers++;
         }
@@ -183,9 +214,9 @@ struct Walker {
             if (shape(fl + nm)[0] != d.ldim) throw Error(PTTS_EFORMAT, strfmt("native varbuilder: tensor \"flow_lm.%s\" shape does not match expected [%d]", nm, d.ldim));
         }
         d.bos = add_f32((size_t)d.ldim, [&](float* dst) { f.decode_f32(fl + "bos_emb", dst); });
-        d.input_linear = linear(fl + "input_linear", true);
+        d.input_linear = step_linear(fl + "input_linear", true);
         d.out_norm = norm(fl + "out_norm", 1e-5f);
-        d.out_eos = linear(fl + "out_eos", true);
+        d.out_eos = step_linear(fl + "out_eos", true);
         // ---------------- flow_net ----------------
         const std::string fn = fl + "flow_net.";
         for (int i = 0; i < 2; i++) {
@@ -197,8 +228,8 @@ struct Walker {
             te.l2 = linear(p + ".mlp.2", true);
             te.alpha = add_f32((size_t)f.at(p + ".mlp.3.alpha").count(), [&](float* dst) { f.decode_f32(p + ".mlp.3.alpha", dst); });
         }
-        d.cond_embed = linear(fn + "cond_embed", true);
-        d.input_proj = linear(fn + "input_proj", true);
+        d.cond_embed = step_linear(fn + "cond_embed", true);
+        d.input_proj = step_linear(fn + "input_proj", true);
         d.flow_dim = d.input_proj.out;
         d.flow_depth = 0;
         for (int i = 0; i < MAX_LAYERS; i++) {
@@ -206,8 +237,8 @@ struct Walker {
             if (!has(p + ".in_ln.weight")) break;
             auto& rb = d.rb[i];
             rb.ln = norm(p + ".in_ln", 1e-6f);
-            rb.mlp0 = linear(p + ".mlp.0", true);
-            rb.mlp2 = linear(p + ".mlp.2", true);
+            rb.mlp0 = step_linear(p + ".mlp.0", true);
+            rb.mlp2 = step_linear(p + ".mlp.2", true);
             d.flow_depth++;
         }
         if (d.flow_depth == 0) throw Error(PTTS_EFORMAT, "native: no flow_net res blocks found");
@@ -230,6 +261,10 @@ struct Walker {
                 size_t o = 0;
                 for (auto& n : names) { f.decode_f32(n + ".weight", dst + o); o += (size_t)f.at(n + ".weight").count(); }
             }, &d.ada_all.bf16);
+            add_tiled(d.ada_all, [&](float* dst) {
+                size_t o = 0;
+                for (auto& n : names) { f.decode_f32(n + ".weight", dst + o); o += (size_t)f.at(n + ".weight").count(); }
+            });
             d.ada_all.b = add_f32((size_t)rows, [&](float* dst) {
                 size_t o = 0;
                 for (auto& n : names) {
@@ -240,7 +275,7 @@ struct Walker {
                 }
             });
         }
-        d.final_linear = linear(fn + "final_layer.linear", true);
+        d.final_linear = step_linear(fn + "final_layer.linear", true);
         // ---------------- mimi ----------------
         const std::string mi = "mimi.";
         {

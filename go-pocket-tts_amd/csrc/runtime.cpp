@@ -15,6 +15,7 @@ static GemmArgs mk(const Model& m, const float* A, RowMap am, const Lin& l, floa
     GemmArgs g;
     g.A = A; g.amap = am;
     g.W = m.arena + l.w; g.w_bf16 = l.bf16; g.ldw = l.in;
+    g.Wt = l.wt == NONE ? nullptr : m.arena + l.wt;
     g.bias = m.at<float>(l.b);
     g.C = C; g.cmap = cm;
     g.M = M; g.N = l.out; g.K = l.in;
@@ -150,12 +151,13 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     const size_t f = sizeof(float);
     const int NA = d.ada_all.out;
     b->in_raw.ensure(B * d.ldim * f); b->in32.ensure(B * d.ldim * f);
-    b->x.ensure(B * d.d_model * f); b->xn.ensure(B * d.d_model * f);
+    b->x.ensure(B * d.d_model * f); b->xn.ensure(B * std::max(d.d_model, d.flow_dim) * f); b->x2.ensure(B * d.d_model * f);
     b->qkv.ensure(B * 3 * d.d_model * f); b->attn.ensure(B * d.d_model * f);
     b->ff.ensure(B * d.ffn * f); b->last.ensure(B * d.d_model * f); b->eos.ensure(B * f);
     b->sy.ensure(B * d.flow_dim * f); b->ada.ensure(B * NA * f);
     b->fx.ensure(B * d.flow_dim * f); b->fh.ensure(B * d.flow_dim * f); b->fh2.ensure(B * d.flow_dim * f);
     b->cur.ensure(B * d.ldim * f);
+    b->partial.ensure((size_t)16 * B * std::max(d.d_model, d.flow_dim) * f);
     b->latents.ensure(B * b->max_steps * d.ldim * f);
     PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t), hipHostMallocDefault));
     batch_reset(*b);
@@ -315,20 +317,86 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
 }
 
 // every linear of the AR step goes through here so that bench.py can time the dominant kernel with HIP events
-static void step_gemm(Model& m, const GemmArgs& g) {
+static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = SkinnyFuse{}, int splitk = 1, float* partial = nullptr) {
+    const bool fused = fu.partial || fu.ln;
+    const bool sk = fused ? skinny_fuse_supported(g, fu) : skinny_supported(g, splitk);
+    if (!sk && (splitk > 1 || fused)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the step kernel");
     Prof& p = m.prof;
-    if (!p.on) { launch_gemm(g, m.stream); return; }
-    while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
-    PTTS_HIP(hipEventRecord(p.ev[p.used], m.stream));
-    launch_gemm(g, m.stream);
-    PTTS_HIP(hipEventRecord(p.ev[p.used + 1], m.stream));
-    p.used += 2;
-    p.launches++;
-    p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 + (double)g.M * g.N * 4;
+    if (p.on) {
+        while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
+        PTTS_HIP(hipEventRecord(p.ev[p.used], m.stream));
+    }
+    if (sk) launch_skinny(g, fu, splitk, partial, m.stream);
+    else launch_gemm(g, m.stream);
+    if (p.on) {
+        PTTS_HIP(hipEventRecord(p.ev[p.used + 1], m.stream));
+        p.used += 2;
+        p.launches++;
+        p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 * (1 + fu.psplit) + (double)g.M * g.N * 4 * (splitk > 1 ? splitk : 1);
+    }
+}
+
+// deferred "x += gate * (sum of split-K partials + bias)": executed by the prologue of the next consumer of x
+struct Pending {
+    const float* partial = nullptr;
+    int splitk = 0;
+    int64_t pstride = 0;
+    const float* bias = nullptr;
+};
+
+static int pick_split(int M, int N, int K) {
+    if (K <= 1024) return 1;   // a whole-K block is one memory burst; splitting pays only when K forces several bursts
+    int need = (K + 1023) / 1024;
+    int blocks = ((N + 63) / 64) * ((M + 15) / 16);
+    int want = (256 + blocks - 1) / blocks;
+    return std::max(need, std::min(want, K / 512));
+}
+
+// one transformer-style block input: rows of x (with a pending residual update) -> LayerNorm -> linear
+struct FusedIn {
+    Pending pend;
+    float* x_out = nullptr;   // where the updated residual goes when pend is set
+    const Norm* norm = nullptr; bool affine = true; float eps = 1e-5f;
+    const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;
+    float* y_out = nullptr;
+};
+
+static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const Lin& l, float* C, int64_t ldc, int M, int epi,
+                              const float* addvec, const float* R, float alpha) {
+    Model& m = *b.m;
+    GemmArgs g = mk(m, x, flat(l.in), l, C, flat(ldc), M);
+    g.epi = epi; g.addvec = addvec; g.R = R; g.alpha = alpha;
+    SkinnyFuse fu;
+    fu.partial = in.pend.partial; fu.psplit = in.pend.splitk; fu.pstride = in.pend.pstride; fu.pbias = in.pend.bias;
+    fu.x_out = in.x_out;
+    fu.ln = 1; fu.eps = in.eps;
+    if (in.norm && in.affine) { fu.ln_w = m.at<float>(in.norm->w); fu.ln_b = m.at<float>(in.norm->b); }
+    fu.shift = in.shift; fu.scale = in.scale; fu.ldmod = in.ldmod;
+    fu.y_out = in.y_out;
+    if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu); return; }
+    // shapes outside the fused kernel (never the reference checkpoint): separate LayerNorm launch, then the linear
+    LnArgs ln;
+    ln.x = x; ln.xmap = flat(l.in); ln.eps = in.eps; ln.rows = M; ln.d = l.in;
+    if (in.norm && in.affine) { ln.w = m.at<float>(in.norm->w); ln.b = m.at<float>(in.norm->b); }
+    ln.shift = in.shift; ln.scale = in.scale; ln.ldmod = in.ldmod;
+    ln.partial = in.pend.partial; ln.splitk = in.pend.splitk; ln.pstride = in.pend.pstride; ln.pbias = in.pend.bias;
+    float* y = in.y_out ? in.y_out : b.xn.as<float>();
+    ln.y = y; ln.ldy = l.in;
+    if (in.pend.partial) {   // the unfused reducer updates x in place; mirror it into x_out for the caller's ping-pong
+        launch_layernorm(ln, m.stream);
+        if (in.x_out && in.x_out != x) PTTS_HIP(hipMemcpyAsync(in.x_out, x, (size_t)M * l.in * sizeof(float), hipMemcpyDeviceToDevice, m.stream));
+    } else launch_layernorm(ln, m.stream);
+    GemmArgs g2 = mk(m, y, flat(l.in), l, C, flat(ldc), M);
+    g2.epi = epi; g2.addvec = addvec; g2.R = R; g2.alpha = alpha;
+    step_gemm(m, g2);
 }
 
 // FlowLM.SampleNextLatentStateful minus the host glue (flow_lm.go:252-288): input_linear, 6 x forwardWithState(Tq=1),
 // out_norm, out_eos, LSD decode through the flow net.  Everything reads device state, so the sequence is graph-capturable.
+// Launch plan per transformer layer: [LN1 + in_proj] -> [RoPE + KV append + attention] -> [out_proj + residual]
+// -> [LN2 + linear1 + GELU] -> [linear2, split over K]; the split-K sum and its residual add ride in the next
+// layer's first launch.  The residual stream ping-pongs between two buffers so that no launch reads rows another
+// block of the same launch rewrites.
 void step_core(Batch& b, int lsd) {
     Model& m = *b.m;
     const Desc& d = m.d;
@@ -336,15 +404,21 @@ void step_core(Batch& b, int lsd) {
     const int B = b.B, D = d.d_model, C = d.flow_dim, NA = d.ada_all.out;
     const bool kvb = m.opts.kv == PTTS_KV_BF16;
     float* x = b.x.as<float>();
-    float* xn = b.xn.as<float>();
+    float* x_alt = b.x2.as<float>();
     float* qkv = b.qkv.as<float>();
     float* attn = b.attn.as<float>();
     float* ff = b.ff.as<float>();
     step_gemm(m, mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B));
+    Pending pend;
     for (int l = 0; l < d.n_layers; l++) {
         const auto& L = d.layers[l];
-        launch_layernorm(mkln(m, x, flat(D), L.n1, xn, D, B), s);
-        step_gemm(m, mk(m, xn, flat(D), L.in_proj, qkv, flat(3 * D), B));
+        {
+            FusedIn in;
+            in.pend = pend; in.x_out = pend.partial ? x_alt : nullptr; in.norm = &L.n1; in.eps = L.n1.eps;
+            step_fused_linear(b, x, in, L.in_proj, qkv, 3 * D, B, EPI_NONE, nullptr, nullptr, 1.0f);
+            if (pend.partial) std::swap(x, x_alt);
+            pend = Pending{};
+        }
         AttnArgs a;
         a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
         a.k_seg_stride = (int64_t)d.heads * b.cap * d.hd; a.k_head_stride = (int64_t)b.cap * d.hd; a.k_row_stride = d.hd;
@@ -355,26 +429,40 @@ void step_core(Batch& b, int lsd) {
         a.fused_step = 1; a.qkv = qkv; a.qkv_ld = 3 * D; a.d_model = D;
         a.cos_t = m.at<float>(d.rope_cos); a.sin_t = m.at<float>(d.rope_sin); a.cap = b.cap;
         launch_attention(a, s);
-        GemmArgs go = mk(m, attn, flat(D), L.out_proj, x, flat(D), B);
-        go.R = x; go.epi = EPI_RESADD;
-        step_gemm(m, go);
-        launch_layernorm(mkln(m, x, flat(D), L.n2, xn, D, B), s);
-        GemmArgs g1 = mk(m, xn, flat(D), L.l1, ff, flat(d.ffn), B);
-        g1.epi = EPI_GELU;
-        step_gemm(m, g1);
-        GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
-        g2.R = x; g2.epi = EPI_RESADD;
-        step_gemm(m, g2);
+        {
+            GemmArgs go = mk(m, attn, flat(D), L.out_proj, x, flat(D), B);
+            go.R = x; go.epi = EPI_RESADD;
+            step_gemm(m, go);
+        }
+        {
+            FusedIn in;
+            in.norm = &L.n2; in.eps = L.n2.eps;
+            step_fused_linear(b, x, in, L.l1, ff, d.ffn, B, EPI_GELU, nullptr, nullptr, 1.0f);
+        }
+        {
+            GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
+            const int S = pick_split(B, D, d.ffn);
+            if (S > 1 && skinny_supported(g2, S)) {
+                step_gemm(m, g2, SkinnyFuse{}, S, b.partial.as<float>());
+                pend.partial = b.partial.as<float>(); pend.splitk = S; pend.pstride = (int64_t)B * D; pend.bias = m.at<float>(L.l2.b);
+            } else {
+                g2.R = x; g2.epi = EPI_RESADD;
+                step_gemm(m, g2);
+            }
+        }
     }
     float* last = b.last.as<float>();
-    launch_layernorm(mkln(m, x, flat(D), d.out_norm, last, D, B), s);
+    {   // out_norm (flow_lm.go:262): standalone, its rows feed two linears and the API
+        LnArgs ln = mkln(m, x, flat(D), d.out_norm, last, D, B);
+        ln.partial = pend.partial; ln.splitk = pend.splitk; ln.pstride = pend.pstride; ln.pbias = pend.bias;
+        launch_layernorm(ln, s);
+    }
     step_gemm(m, mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B));
     // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
     const float* tc = m.tcomb.at(lsd)->as<float>();
     float* sy = b.sy.as<float>();
     float* ada = b.ada.as<float>();
     float* fx = b.fx.as<float>();
-    float* fh = b.fh.as<float>();
     float* fh2 = b.fh2.as<float>();
     float* cur = b.cur.as<float>();
     for (int i = 0; i < lsd; i++) {
@@ -385,23 +473,18 @@ void step_core(Batch& b, int lsd) {
         step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
         for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
             const auto& rb = d.rb[r];
-            LnArgs ln = mkln(m, fx, flat(C), rb.ln, fh, C, B);
-            ln.shift = ada + (size_t)r * 3 * C; ln.scale = ln.shift + C; ln.ldmod = NA;
-            launch_layernorm(ln, s);
-            GemmArgs g0 = mk(m, fh, flat(C), rb.mlp0, fh2, flat(C), B);
-            g0.epi = EPI_SILU;
-            step_gemm(m, g0);
+            FusedIn in;
+            in.norm = &rb.ln; in.eps = rb.ln.eps;
+            in.shift = ada + (size_t)r * 3 * C; in.scale = in.shift + C; in.ldmod = NA;
+            step_fused_linear(b, fx, in, rb.mlp0, fh2, C, B, EPI_SILU, nullptr, nullptr, 1.0f);
             GemmArgs g2 = mk(m, fh2, flat(C), rb.mlp2, fx, flat(C), B);
             g2.R = fx; g2.epi = EPI_GATE_RESADD; g2.gate = ada + (size_t)r * 3 * C + 2 * C; g2.ldg = NA;
             step_gemm(m, g2);
         }
-        LnArgs lf;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
-        lf.x = fx; lf.xmap = flat(C); lf.eps = 1e-6f; lf.y = fh; lf.ldy = C; lf.rows = B; lf.d = C;
-        lf.shift = ada + (size_t)d.flow_depth * 3 * C; lf.scale = lf.shift + C; lf.ldmod = NA;
-        launch_layernorm(lf, s);
-        GemmArgs gf = mk(m, fh, flat(C), d.final_linear, cur, flat(d.ldim), B);  // current += flow * (1/steps)
-        gf.R = cur; gf.epi = EPI_AXPY; gf.alpha = 1.0f / (float)lsd;
-        step_gemm(m, gf);
+        FusedIn fin;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
+        fin.affine = false; fin.eps = 1e-6f;
+        fin.shift = ada + (size_t)d.flow_depth * 3 * C; fin.scale = fin.shift + C; fin.ldmod = NA;
+        step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd);  // current += flow / steps
     }
 }
 

@@ -76,7 +76,7 @@ struct Batch {
     StepState st{};
     std::vector<int32_t> kv_len_host;
     // step workspace
-    DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step;
+    DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step, partial, x2;
     DevBuf latents;          // [B][max_steps][ldim]
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;
