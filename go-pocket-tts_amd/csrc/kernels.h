@@ -126,7 +126,9 @@ struct AttnArgs {
     const float* cos_t = nullptr; const float* sin_t = nullptr; int64_t cap = 0;
     const int32_t* active = nullptr;    // per segment; inactive rows write zeros and append nothing
 };
-void launch_attention(const AttnArgs& a, hipStream_t stream);
+void launch_attention(const AttnArgs& a, hipStream_t stream);   // picks k_attn_step for the fused AR step when the cache fits one burst
+bool attn_step_supported(const AttnArgs& a);
+void launch_attn_step(const AttnArgs& a, hipStream_t stream);
 
 // latent [B, T, L] -> x[b, 1+t, :] = Wp * latent + bp  (model.go:252-319), row 0 of each utterance zeroed
 void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c,

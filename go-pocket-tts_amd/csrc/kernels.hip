@@ -444,6 +444,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (a.rows <= 0) return;
+    if (attn_step_supported(a)) { launch_attn_step(a, stream); return; }
     const int wpq = a.fused_step ? 4 : (a.rows * a.heads < 2048 ? 4 : 1);
     const int qpb = 4 / wpq;
     size_t lds = ((size_t)qpb * a.max_keys + (size_t)qpb * wpq * 64 + 64) * sizeof(float);

@@ -319,8 +319,10 @@ def test_ragged_batch_equals_single_requests(pkg, tiny):
     for i in range(4):
         one = gm.generate_batch([toks[i]], [cfgs[i]])[0]
         assert batch[i].n_frames == one.n_frames and batch[i].eos_step == one.eos_step
-        parity(f"batch vs single latents {i}", batch[i].latents, one.latents, (1e-5, 1e-3))
-        parity(f"batch vs single pcm {i}", batch[i].pcm, one.pcm, (1e-5, 1e-2))
+        # not bitwise: tile / kernel selection depends on the number of rows in flight (f32-MFMA vs bf16-split GEMM,
+        # 1 vs 4 waves per attention query), which changes summation order and the last bits
+        parity(f"batch vs single latents {i}", batch[i].latents, one.latents, (1e-4, 5e-3))
+        parity(f"batch vs single pcm {i}", batch[i].pcm, one.pcm, (1e-4, 5e-2))
     ref1 = om.generate(toks[1], max_steps=8, eos_threshold=thr, frames_after_eos=2)
     assert batch[1].n_frames == ref1["n_frames"] and batch[1].eos_step == ref1["eos_step"]
 
