@@ -66,6 +66,20 @@ def voice_modules(pkg, cfg):
     return mods
 
 
+def shard_prompts(all_prompts, rank: int, per_rank: int):
+    """Utterance chunks are independent (service.go:138-153): rank r owns rows [r*per_rank, (r+1)*per_rank). No exchange."""
+    return all_prompts[rank * per_rank:(rank + 1) * per_rank]
+
+
+def max_over_ranks(value: float, world: int, device=None) -> float:
+    if world == 1:
+        return value
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def open_model(pkg, path, wl, rank, world, device):
     """Two-phase open: rank 0 fills the device arena, one RCCL broadcast hands it to the other ranks."""
     kw = dict(device=device, weights=wl["weights"], kv=wl["kv"], max_batch=wl["batch"], use_graph=True)
@@ -192,14 +206,10 @@ def main():
     log(f"[bench] rank {rank}: model resident in {time.time()-t0:.1f}s ({model.info.arena_bytes/1e6:.0f} MB arena, {model.info.n_params/1e6:.1f} M params)")
     voice = model.upload_voice(pkg.VoiceModelState(voice_modules(pkg, cfg)))
     all_prompts = pkg.synth.make_prompts(wl["batch"] * world, 25, 4000, seed=42)
-    prompts = all_prompts[rank * wl["batch"]:(rank + 1) * wl["batch"]]     # utterances are dealt to ranks; no exchange
+    prompts = shard_prompts(all_prompts, rank, wl["batch"])
 
     elapsed, lat, frames = run_workload(pkg, model, wl, prompts, voice, args.steps, args.warmup, barrier, sync)
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(elapsed, world, f"cuda:{local}")
     audio_s = wl["batch"] * world * wl["frames"] * FRAME_SEC * args.steps
     result = {
         "metric": "synthesized audio sec/sec (xRT)", "value": round(audio_s / elapsed, 1), "unit": "x real-time",

@@ -100,6 +100,14 @@ int ptts_plan_create_bytes(const void* data, size_t len, const ptts_opts* opts, 
 }
 
 size_t ptts_plan_arena_bytes(const ptts_plan* p) { return p ? p->p.desc.total_bytes : 0; }
+
+int ptts_plan_fill_host(const ptts_plan* p, void* host_arena) {
+    return guard([&] {
+        if (!p || !host_arena) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::memset(host_arena, 0, p->p.desc.total_bytes);
+        plan_fill(p->p, reinterpret_cast<uint8_t*>(host_arena));
+    });
+}
 void ptts_plan_free(ptts_plan* p) { delete p; }
 
 int ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_model** out) {

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
     "ptts_decode_latents", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
-    "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read",
+    "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host",
 ]
 
 
@@ -121,6 +121,7 @@ def lib():
         L.ptts_plan_create.argtypes = [C.c_char_p, C.POINTER(_Opts), C.POINTER(C.c_void_p)]
         L.ptts_plan_create_bytes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(_Opts), C.POINTER(C.c_void_p)]
         L.ptts_model_open_planned.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+        L.ptts_plan_fill_host.argtypes = [C.c_void_p, C.c_void_p]
         L.ptts_model_info.argtypes = [C.c_void_p, C.POINTER(_Info)]
         L.ptts_generate.argtypes = [C.c_void_p, C.POINTER(_Request), C.c_int32, C.POINTER(_Result)]
         L.ptts_free_result.argtypes = [C.POINTER(_Result)]
@@ -258,6 +259,17 @@ class Model:
         o = _opts(**kw)
         _check(lib().ptts_plan_create(path.encode(), C.byref(o), C.byref(p)))
         return p.value, int(lib().ptts_plan_arena_bytes(p.value))
+
+    @staticmethod
+    def plan_fill_host(plan: int, nbytes: int) -> np.ndarray:
+        """Host image of the arena (decode + convert + derive), no GPU needed."""
+        buf = np.zeros(nbytes, np.uint8)
+        _check(lib().ptts_plan_fill_host(plan, buf.ctypes.data_as(C.c_void_p)))
+        return buf
+
+    @staticmethod
+    def plan_free(plan: int):
+        lib().ptts_plan_free(plan)
 
     @staticmethod
     def open_planned(plan: int, device_arena_ptr: int, fill: bool) -> "Model":

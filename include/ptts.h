@@ -87,6 +87,8 @@ int    ptts_plan_create(const char* safetensors_path, const ptts_opts* opts, ptt
 int    ptts_plan_create_bytes(const void* data, size_t len, const ptts_opts* opts, ptts_plan** out);
 size_t ptts_plan_arena_bytes(const ptts_plan* p);
 int    ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_model** out); /* consumes p */
+/* host image of the arena (ptts_plan_arena_bytes() bytes), for hosts that upload / broadcast it themselves; needs no GPU */
+int    ptts_plan_fill_host(const ptts_plan* p, void* host_arena);
 void   ptts_plan_free(ptts_plan* p);
 
 /* ---- the Runtime seam: tts.Runtime.GenerateAudio (runtime_native_safetensors.go:52-238) ---- */
