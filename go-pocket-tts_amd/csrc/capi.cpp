@@ -488,6 +488,58 @@ int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int3
     });
 }
 
+// debug: time one many-row GEMM variant (2 = k_gemm2, 3 = k_gemm3) and compare it with the other one on pseudo-random data
+int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us, float* maxdiff) {
+    return guard([&] {
+        require_device();
+        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+        std::vector<float> ha(na), hw(nw), hb((size_t)N);
+        uint32_t st = 12345u;
+        auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((float)(st >> 8) / 8388608.0f) - 1.0f; };
+        for (auto& x : ha) x = rnd();
+        for (auto& x : hw) x = rnd() * 0.05f;
+        for (auto& x : hb) x = rnd();
+        Tmp dA(na * 4), dW(nw * 4), dB((size_t)N * 4), dC(nc * 4), dC2(nc * 4), dR(nc * 4);
+        up(dA.p, ha.data(), na * 4); up(dB.p, hb.data(), (size_t)N * 4);
+        if (w_bf16) {
+            std::vector<uint16_t> hw16(nw);
+            for (size_t i = 0; i < nw; i++) { uint32_t u; memcpy(&u, &hw[i], 4); hw16[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
+            up(dW.p, hw16.data(), nw * 2);
+        } else up(dW.p, hw.data(), nw * 4);
+        PTTS_HIP(hipMemset(dR.p, 0, nc * 4));
+        GemmArgs g;
+        g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
+        g.W = dW.p; g.w_bf16 = w_bf16; g.ldw = K; g.bias = dB.as<float>();
+        g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
+        g.R = dR.as<float>(); g.epi = epi;
+        g.M = M; g.N = N; g.K = K;
+        if (!gemm2_supported(g) || !gemm3_supported(g)) throw Error(PTTS_EINVAL, "shape not supported");
+        auto run = [&](int v, float* c) { GemmArgs h = g; h.C = c; if (v >= 3) { g_gemm3_cfg = v >= 30 ? v - 30 : 0; launch_gemm3(h, nullptr); g_gemm3_cfg = 0; } else launch_gemm2(h, nullptr); };
+        hipEvent_t e0, e1;
+        PTTS_HIP(hipEventCreate(&e0)); PTTS_HIP(hipEventCreate(&e1));
+        for (int i = 0; i < 2; i++) run(variant, dC.as<float>());
+        PTTS_HIP(hipDeviceSynchronize());
+        PTTS_HIP(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; i++) run(variant, dC.as<float>());
+        PTTS_HIP(hipEventRecord(e1, nullptr));
+        PTTS_HIP(hipEventSynchronize(e1));
+        float ms = 0;
+        PTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
+        *avg_us = ms * 1e3f / (float)iters;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        *maxdiff = -1.0f;
+        if (nc <= ((size_t)64 << 20)) {
+            run(variant >= 3 ? 2 : 3, dC2.as<float>());
+            PTTS_HIP(hipDeviceSynchronize());
+            std::vector<float> c1(nc), c2(nc);
+            down(c1.data(), dC.p, nc * 4); down(c2.data(), dC2.p, nc * 4);
+            float md = 0;
+            for (size_t i = 0; i < nc; i++) { float d = std::fabs(c1[i] - c2[i]); if (!(d <= md)) md = d; }
+            *maxdiff = md;
+        }
+    });
+}
+
 int ptts_op_linear(const float* x, const float* w, const float* bias, int64_t rows, int64_t in, int64_t out, float* y) {
     return guard([&] {
         require_device();
@@ -536,7 +588,7 @@ int ptts_op_rope(float* x, const float* cos_t, const float* sin_t, int64_t table
         size_t n = (size_t)prefix * seq * dim, tn = (size_t)table_rows * (dim / 2);
         Tmp dx(n * 4), dc(tn * 4), ds(tn * 4);
         up(dx.p, x, n * 4); up(dc.p, cos_t, tn * 4); up(ds.p, sin_t, tn * 4);
-        launch_rope_rows(dx.as<float>(), dim, 0, 1, (int)dim, nullptr, (int)pos, (int)seq, (int)(prefix * seq), dc.as<float>(), ds.as<float>(), nullptr);
+        launch_rope_rows(dx.as<float>(), RowMap{dim, 0, 0}, 0, 1, (int)dim, nullptr, (int)pos, (int)seq, (int)(prefix * seq), dc.as<float>(), ds.as<float>(), nullptr);
         PTTS_HIP(hipDeviceSynchronize());
         down(x, dx.p, n * 4);
     });
@@ -659,7 +711,7 @@ int ptts_op_convtr1d_righttrim(const float* x, const float* w, const float* bias
             if (bias) up(db.p, bias, (size_t)cin * 4);
             PTTS_HIP(hipMemset(dxc.p, 0, (size_t)b * (1 + len) * cin * 4));
             launch_bct_to_btc(dx.as<float>(), (int)b, (int)cin, (int)len, dxc.as<float>(), 1, nullptr);
-            launch_upsample_depthwise(dxc.as<float>(), d0.as<float>(), d1.as<float>(), bias ? db.as<float>() : nullptr, (int)b, (int)len,
+            launch_upsample_depthwise(dxc.as<float>(), d0.as<float>(), d1.as<float>(), bias ? db.as<float>() : nullptr, (int)b, (int)len, 0, (int)len,
                                       (int)cin, (int)stride, dyc.as<float>(), 0, nullptr);
             launch_btc_to_bct(dyc.as<float>(), 0, (int)b, (int)cin, (int)lout, dy.as<float>(), nullptr);
             PTTS_HIP(hipDeviceSynchronize());

@@ -12,11 +12,17 @@ namespace ptts {
 #define WAVE 64
 
 __device__ __forceinline__ int64_t row_off(const RowMap& m, int64_t r) {
-    return m.rows_per_batch ? (r / m.rows_per_batch) * m.batch_stride + (r % m.rows_per_batch) * m.ld : r * m.ld;
+    if (!m.rows_per_batch) return r * m.ld;
+    const unsigned rpb = (unsigned)m.rows_per_batch, ru = (unsigned)r;   // row counts fit in 32 bits: avoid the 64-bit divide
+    const unsigned b = ru / rpb, t = ru - b * rpb;
+    return (int64_t)b * m.batch_stride + (int64_t)t * m.ld;
 }
 
 __device__ __forceinline__ float elu1(float v) { return v <= 0.0f ? expf(v) - 1.0f : v; }        // tensor_util.go:119-128
 __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); }                  // tensor_util.go:73-82
+// ELU on the hardware exponential (v_exp_f32 of v*log2(e)): |error| < 2e-7 absolute on (-inf, 0], below the rounding noise of the
+// bf16-split products it feeds; used where ELU sits in a GEMM prologue/epilogue and is evaluated millions of times per launch
+__device__ __forceinline__ float elu_fast(float v) { return v <= 0.0f ? __expf(v) - 1.0f : v; }
 __device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // :84-94
 
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }

@@ -27,6 +27,7 @@ enum Epi : int {
     EPI_SCALE_RESADD,    // C = R + scale[n] * (acc + bias)              mimi.go:275-285,351-358
     EPI_GATE_RESADD,     // C = R + gate[m, n] * (acc + bias)            flow_net.go:166-171
     EPI_AXPY,            // C = R + alpha * (acc + bias)                 flow_lm.go:346-349
+    EPI_RESADD_ELU,      // C = elu(R + (acc + bias))   SEANet residual sum whose every reader applies ELU first (mimi.go:146-164,752-783)
 };
 
 struct GemmArgs {
@@ -47,6 +48,9 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t stream);   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
 bool gemm2_supported(const GemmArgs& a);
 void launch_gemm2(const GemmArgs& a, hipStream_t stream);
+bool gemm3_supported(const GemmArgs& a);   // direct-to-register activations, 256-row blocks (gemm3.hip)
+void launch_gemm3(const GemmArgs& a, hipStream_t stream);
+extern int g_gemm3_cfg;
 
 // Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.
@@ -99,7 +103,7 @@ void launch_avg2(const float* a, const float* b, float* y, int n, hipStream_t st
 // interleaved-pair RoPE (rope.go:81-105) on rows of a [rows, ld] buffer: for each row r and head h the
 // vector at x + r*ld + col0 + h*hd is rotated with the table row pos[r]
 // position of row r: pos ? pos[r] : pos_base + (rows_per_seg ? r % rows_per_seg : r)
-void launch_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
+void launch_rope_rows(float* x, RowMap xmap, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
                       int rows, const float* cos_t, const float* sin_t, hipStream_t stream);
 
 // KV cache layout: [slot][head][capacity][hd]; append K/V rows taken from a qkv buffer [rows, 3*D]
@@ -109,7 +113,9 @@ void launch_kv_append(const float* qkv, int64_t ld, int d_model, int heads, int 
 
 struct AttnArgs {
     // one query per (row, head)
-    const float* q = nullptr; int64_t q_ld = 0; int q_col0 = 0;   // q vector at q + row*q_ld + q_col0 + h*hd
+    const float* q = nullptr; int64_t q_ld = 0; int q_col0 = 0;   // q vector at q + rowaddr(row) + q_col0 + h*hd
+    int64_t q_rows_per_batch = 0, q_batch_stride = 0;             // RowMap of the q rows (0: flat, row*q_ld)
+    int pos_base = 0;                                             // added to the implicit position (row % rows_per_seg)
     // keys/values: key j of (row, head) at kbase + seg(row)*k_seg_stride + h*k_head_stride + j*k_row_stride
     const void* k = nullptr; const void* v = nullptr; int kv_bf16 = 0;
     int64_t k_seg_stride = 0, k_head_stride = 0, k_row_stride = 0;
@@ -118,7 +124,8 @@ struct AttnArgs {
     const int32_t* row_pos = nullptr;   // query position; null: pos = row % rows_per_seg
     const int32_t* seg_len = nullptr;   // if set (AR step): pos = seg_len[seg], rope+append fused
     int context = -1;                   // keys j with pos-context < j <= pos   (attention.go:473-484)
-    float* out = nullptr; int64_t out_ld = 0;  // out + row*out_ld + h*hd
+    float* out = nullptr; int64_t out_ld = 0;  // out + rowaddr(row) + h*hd
+    int64_t o_rows_per_batch = 0, o_batch_stride = 0;
     int rows = 0, heads = 0, hd = 64;
     int max_keys = 0;                   // upper bound on keys per query (sizes the LDS score buffer)
     // fused RoPE + KV append for the AR step (flow_transformer.go:340-347): q,k,v read from a qkv row
@@ -129,14 +136,16 @@ struct AttnArgs {
 void launch_attention(const AttnArgs& a, hipStream_t stream);   // picks k_attn_step for the fused AR step when the cache fits one burst
 bool attn_step_supported(const AttnArgs& a);
 void launch_attn_step(const AttnArgs& a, hipStream_t stream);
+bool attn_window_supported(const AttnArgs& a);   // Mimi sliding-window attention on the f32 matrix cores
+void launch_attn_window(const AttnArgs& a, hipStream_t stream);
 
 // latent [B, T, L] -> x[b, 1+t, :] = Wp * latent + bp  (model.go:252-319), row 0 of each utterance zeroed
-void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c,
-                      float* out, hipStream_t stream);
+void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
+                      int ldim, int c, float* out, hipStream_t stream);   // frames [f0, f1) -> rows 1+f of out [B][1+t][c]
 // depthwise ConvTranspose1d k=2*stride, right-trimmed (convtranspose1d.go:154-202): in [B, 1+T, C] (row 0 = zeros) ->
 // out rows [B][pad + T*stride][C]; w0[r][c] multiplies x[t-1], w1[r][c] multiplies x[t]
-void launch_upsample_depthwise(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int c,
-                               int stride, float* out, int out_pad_rows, hipStream_t stream);
+void launch_upsample_depthwise(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int f0, int f1,
+                               int c, int stride, float* out, int out_pad_rows, hipStream_t stream);   // frames [f0, f1)
 // voice model-state ingestion (flow_transformer.go:568-631): raw [2,1,T,H,D] f32 -> first `offset` rows of a slot's K and V cache
 void launch_voice_scatter(const float* raw, int t, int heads, int hd, int offset, int slot, void* kcache, void* vcache,
                           int kv_bf16, int64_t cap, hipStream_t stream);
@@ -144,8 +153,8 @@ void launch_voice_scatter(const float* raw, int t, int heads, int hd, int offset
 void launch_voice_apply(const void* vk, const void* vv, int offset, int heads, int hd, const int32_t* slots, int n_slots,
                         void* kcache, void* vcache, int elem_bytes, int64_t cap, hipStream_t stream);
 // final causal conv Cin -> 1, kernel k, ELU on the input (mimi.go:781-783): in [B][pad+T][C] channels-last
-void launch_conv_final(const float* in, int in_pad_rows, const float* w /*[k*C]*/, const float* bias, int b, int t, int c,
-                       int k, float* out /*[B][T]*/, hipStream_t stream);
+void launch_conv_final(const float* in, int in_pad_rows, const float* w /*[k*C]*/, const float* bias, int b, int t, int t0, int t1,
+                       int c, int k, int elu_in /* 0: the producer already applied ELU */, float* out /*[B][T]*/, hipStream_t stream);   // samples [t0, t1) of every utterance
 void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipStream_t stream);
 
 // AR-step bookkeeping (runtime_native_safetensors.go:176-192 per slot, on device)

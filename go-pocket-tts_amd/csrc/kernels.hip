@@ -4,6 +4,7 @@
 // Layout conventions: activations are row-major [rows, channels] ("channels-last" for the
 // Mimi decoder, so that a causal convolution window is one contiguous span and every
 // global access is a coalesced 16-byte-per-lane stream); weights are [out, in] row-major.
+#include <cstdlib>
 #include "kernels.h"
 #include "device_util.h"
 
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
             case EPI_SCALE_RESADD: v = a.R[co] + scl * v; break;
             case EPI_GATE_RESADD: v = a.R[co] + a.gate[(int64_t)m * a.ldg + n] * v; break;
             case EPI_AXPY: v = a.R[co] + a.alpha * v; break;
+            case EPI_RESADD_ELU: v = elu1(a.R[co] + v); break;
         }
         a.C[co] = v;
     }
@@ -142,6 +144,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
 
 void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return;
+    static const int force = [] { const char* e = getenv("PTTS_GEMM"); return e ? atoi(e) : 0; }();   // A/B measurement only
+    if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;
     int w_vec = a.w_bf16 ? ((reinterpret_cast<uintptr_t>(a.W) & 7) == 0 && a.ldw % 4 == 0) : (aligned16(a.W) && a.ldw % 4 == 0);
@@ -233,7 +237,7 @@ void launch_add_i32(int32_t* p, const int32_t* inc, int n, hipStream_t stream) {
 // ------------------------------------------------------------------------------------------------
 // RoPE on rows of a qkv buffer (K5; rope.go:81-105): interleaved pairs, table row = position
 // ------------------------------------------------------------------------------------------------
-__global__ void k_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, const int32_t* pos, int pos_base,
+__global__ void k_rope_rows(float* x, RowMap xmap, int col0, int heads, int hd, const int32_t* pos, int pos_base,
                             int rows_per_seg, int rows, const float* cos_t, const float* sin_t) {
     const int half = hd / 2;
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -243,17 +247,17 @@ __global__ void k_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, c
     int h = (int)((i / half) % heads);
     int r = (int)(i / ((int64_t)half * heads));
     int p = pos ? pos[r] : pos_base + (rows_per_seg ? r % rows_per_seg : r);
-    float* v = x + (int64_t)r * ld + col0 + h * hd + 2 * j;
+    float* v = x + row_off(xmap, r) + col0 + h * hd + 2 * j;
     float a = v[0], b = v[1];
     float c = cos_t[(int64_t)p * half + j], s = sin_t[(int64_t)p * half + j];
     v[0] = a * c - b * s;
     v[1] = a * s + b * c;
 }
-void launch_rope_rows(float* x, int64_t ld, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
+void launch_rope_rows(float* x, RowMap xmap, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
                       int rows, const float* cos_t, const float* sin_t, hipStream_t stream) {
     int64_t tot = (int64_t)rows * heads * (hd / 2);
     if (tot <= 0) return;
-    hipLaunchKernelGGL(k_rope_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, x, ld, col0, heads, hd, pos,
+    hipLaunchKernelGGL(k_rope_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, x, xmap, col0, heads, hd, pos,
                        pos_base, rows_per_seg, rows, cos_t, sin_t);
 }
 
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     int seg = 0, pos = -1;
     if (row_ok) {
         seg = a.row_seg ? a.row_seg[row] : (a.rows_per_seg ? row / a.rows_per_seg : row);
-        pos = a.seg_len ? a.seg_len[seg] : (a.row_pos ? a.row_pos[row] : (a.rows_per_seg ? row % a.rows_per_seg : row));
+        pos = a.seg_len ? a.seg_len[seg] : (a.row_pos ? a.row_pos[row] : a.pos_base + (a.rows_per_seg ? row % a.rows_per_seg : row));
     }
     const bool live = row_ok && (!a.active || a.active[seg]);
     const char* kbase = (const char*)a.k + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * (KVBF16 ? 2 : 4);
@@ -369,7 +373,7 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) {
         if (a.fused_step) q4 = *reinterpret_cast<const float4*>(qs + sub * 4);
-        else q4 = *reinterpret_cast<const float4*>(a.q + (int64_t)row * a.q_ld + a.q_col0 + h * 64 + sub * 4);
+        else q4 = *reinterpret_cast<const float4*>(a.q + row_off(RowMap{a.q_ld, a.q_rows_per_batch, a.q_batch_stride}, row) + a.q_col0 + h * 64 + sub * 4);
     }
     const float scale = 0.125f;  // 1/sqrt(64)
 
@@ -438,13 +442,14 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     if (row_ok && wq == 0 && kq == 0) {
         float inv = (nk > 0 && sum > 0.0f) ? 1.0f / sum : 0.0f;
         float4 r = nk > 0 ? make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(a.out + (int64_t)row * a.out_ld + h * 64 + sub * 4) = r;
+        *reinterpret_cast<float4*>(a.out + row_off(RowMap{a.out_ld, a.o_rows_per_batch, a.o_batch_stride}, row) + h * 64 + sub * 4) = r;
     }
 }
 
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (a.rows <= 0) return;
     if (attn_step_supported(a)) { launch_attn_step(a, stream); return; }
+    if (attn_window_supported(a)) { launch_attn_window(a, stream); return; }
     const int wpq = a.fused_step ? 4 : (a.rows * a.heads < 2048 ? 4 : 1);
     const int qpb = 4 / wpq;
     size_t lds = ((size_t)qpb * a.max_keys + (size_t)qpb * wpq * 64 + 64) * sizeof(float);
@@ -462,39 +467,39 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
 // Mimi front end
 // ------------------------------------------------------------------------------------------------
 // K13: latent -> mimi projector with emb_std/emb_mean folded in (model.go:226-242,294-303)
-__global__ void k_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c, float* out) {
+__global__ void k_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
+                            int ldim, int c, float* out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t tot = (int64_t)b * (t + 1) * c;
+    const int nf = f1 - f0;
+    int64_t tot = (int64_t)b * nf * c;
     if (i >= tot) return;
     int oc = (int)(i % c);
-    int tt = (int)((i / c) % (t + 1));
-    int bi = (int)(i / ((int64_t)c * (t + 1)));
-    float v = 0.0f;
-    if (tt > 0) {
-        const float* l = latent + (int64_t)bi * lat_bstride + (int64_t)(tt - 1) * ldim;
-        const float* w = wp + (int64_t)oc * ldim;
-        float s = 0.0f;
-        for (int k = 0; k < ldim; k++) s += l[k] * w[k];
-        v = s + bp[oc];
-    }
-    out[i] = v;
+    int f = f0 + (int)((i / c) % nf);
+    int bi = (int)(i / ((int64_t)c * nf));
+    const float* l = latent + (int64_t)bi * lat_bstride + (int64_t)f * ldim;
+    const float* w = wp + (int64_t)oc * ldim;
+    float s = 0.0f;
+    for (int k = 0; k < ldim; k++) s += l[k] * w[k];
+    out[((int64_t)bi * (t + 1) + 1 + f) * c + oc] = s + bp[oc];   // row 0 of every utterance is the zero history row
 }
-void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int ldim, int c,
-                      float* out, hipStream_t stream) {
-    int64_t tot = (int64_t)b * (t + 1) * c;
-    hipLaunchKernelGGL(k_projector, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, latent, lat_bstride, wp, bp, b, t, ldim, c, out);
+void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
+                      int ldim, int c, float* out, hipStream_t stream) {
+    int64_t tot = (int64_t)b * (f1 - f0) * c;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(k_projector, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, latent, lat_bstride, wp, bp, b, t, f0, f1, ldim, c, out);
 }
 
 // K14: depthwise transposed conv, k = 2*stride, first T*stride outputs kept (convtranspose1d.go:154-202, mimi.go:116-125)
-__global__ void k_upsample_dw(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int c, int stride,
-                              float* out, int pad) {
+__global__ void k_upsample_dw(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int f0, int f1, int c,
+                              int stride, float* out, int pad) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    int64_t tot = (int64_t)b * t * stride * c;
+    const int nf = f1 - f0;
+    int64_t tot = (int64_t)b * nf * stride * c;
     if (i >= tot) return;
     int ch = (int)(i % c);
     int r = (int)((i / c) % stride);
-    int tt = (int)((i / ((int64_t)c * stride)) % t);
-    int bi = (int)(i / ((int64_t)c * stride * t));
+    int tt = f0 + (int)((i / ((int64_t)c * stride)) % nf);
+    int bi = (int)(i / ((int64_t)c * stride * nf));
     const float* x = in + ((int64_t)bi * (t + 1) + tt) * c + ch;  // x[0] = frame t-1 (row 0 is the zero row), x[c] = frame t
     float prev = x[0] * w0[r * c + ch];
     float cur = x[c] * w1[r * c + ch];
@@ -502,10 +507,11 @@ __global__ void k_upsample_dw(const float* in, const float* w0, const float* w1,
     if (bias) v += bias[ch];
     out[((int64_t)bi * (pad + (int64_t)t * stride) + pad + (int64_t)tt * stride + r) * c + ch] = v;
 }
-void launch_upsample_depthwise(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int c,
-                               int stride, float* out, int out_pad_rows, hipStream_t stream) {
-    int64_t tot = (int64_t)b * t * stride * c;
-    hipLaunchKernelGGL(k_upsample_dw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, w0, w1, bias, b, t, c, stride, out, out_pad_rows);
+void launch_upsample_depthwise(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int f0, int f1,
+                               int c, int stride, float* out, int out_pad_rows, hipStream_t stream) {
+    int64_t tot = (int64_t)b * (f1 - f0) * stride * c;
+    if (tot <= 0) return;
+    hipLaunchKernelGGL(k_upsample_dw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, w0, w1, bias, b, t, f0, f1, c, stride, out, out_pad_rows);
 }
 
 template <bool KVBF16>
@@ -563,12 +569,12 @@ void launch_voice_apply(const void* vk, const void* vv, int offset, int heads, i
 // utterance: the (256 + k - 1) x C input window is one contiguous span in the channels-last buffer, staged into LDS with
 // coalesced 16-byte loads (ELU applied on the way); each thread then reduces its k*C window from LDS.  Rows are padded
 // by one float so that the 64 lanes (64 consecutive rows) read 64 different banks.
-__global__ __launch_bounds__(256) void k_conv_final(const float* in, int pad, const float* w, const float* bias, int b, int t, int c,
-                                                    int k, float* out) {
+__global__ __launch_bounds__(256) void k_conv_final(const float* in, int pad, const float* w, const float* bias, int b, int t, int ta, int tb,
+                                                    int c, int k, int elu_in, float* out) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [(256 + k - 1)][c + 1], then w[k * c]
-    const int tiles_per_b = (t + 255) / 256;
-    const int bi = blockIdx.x / tiles_per_b, t0 = (blockIdx.x % tiles_per_b) * 256;
-    const int rows = min(256, t - t0) + k - 1;
+    const int tiles_per_b = (tb - ta + 255) / 256;
+    const int bi = blockIdx.x / tiles_per_b, t0 = ta + (blockIdx.x % tiles_per_b) * 256;
+    const int rows = min(256, tb - t0) + k - 1;
     const int ld = c + 1;
     float* wl = tile + (256 + k - 1) * ld;
     const float* src = in + ((int64_t)bi * (pad + t) + pad + t0 - (k - 1)) * c;
@@ -577,12 +583,13 @@ __global__ __launch_bounds__(256) void k_conv_final(const float* in, int pad, co
         float4 v = reinterpret_cast<const float4*>(src)[i];
         int r = (i * 4) / c, col = (i * 4) % c;
         float* d = tile + r * ld + col;
-        d[0] = elu1(v.x); d[1] = elu1(v.y); d[2] = elu1(v.z); d[3] = elu1(v.w);
+        if (elu_in) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     for (int i = threadIdx.x; i < k * c; i += 256) wl[i] = w[i];
     __syncthreads();
     const int tt = t0 + threadIdx.x;
-    if (tt >= t) return;
+    if (tt >= tb) return;
     float s = 0.0f;
     for (int x = 0; x < k; x++) {
         const float* row = tile + (threadIdx.x + x) * ld;
@@ -591,11 +598,12 @@ __global__ __launch_bounds__(256) void k_conv_final(const float* in, int pad, co
     }
     out[(int64_t)bi * t + tt] = s + (bias ? bias[0] : 0.0f);
 }
-void launch_conv_final(const float* in, int in_pad_rows, const float* w, const float* bias, int b, int t, int c, int k,
-                       float* out, hipStream_t stream) {
-    const int tiles = (t + 255) / 256;
+void launch_conv_final(const float* in, int in_pad_rows, const float* w, const float* bias, int b, int t, int t0, int t1, int c, int k,
+                       int elu_in, float* out, hipStream_t stream) {
+    const int tiles = (t1 - t0 + 255) / 256;
+    if (tiles <= 0) return;
     size_t lds = ((size_t)(256 + k - 1) * (c + 1) + (size_t)k * c) * sizeof(float);
-    hipLaunchKernelGGL(k_conv_final, dim3((unsigned)(b * tiles)), dim3(256), lds, stream, in, in_pad_rows, w, bias, b, t, c, k, out);
+    hipLaunchKernelGGL(k_conv_final, dim3((unsigned)(b * tiles)), dim3(256), lds, stream, in, in_pad_rows, w, bias, b, t, t0, t1, c, k, elu_in, out);
 }
 
 __global__ void k_zero_rows(float* base, int64_t batch_stride, int b, int64_t n) {

@@ -47,6 +47,8 @@ static void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 Model::~Model() {
     for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    if (stream2) (void)hipStreamDestroy(stream2);
     cached_batch.reset();
     tcomb.clear();
     ws.clear();
@@ -65,7 +67,12 @@ Model* model_open(Plan* plan, void* device_arena, int fill) {
     m->opts = plan->opts;
     m->device = plan->opts.device;
     m->use_device();
-    PTTS_HIP(hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking));
+    {
+        int lo = 0, hi = 0;   // numerically lower = higher priority
+        PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        PTTS_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi));
+        PTTS_HIP(hipStreamCreateWithPriority(&m->stream2, hipStreamNonBlocking, lo));
+    }
     if (device_arena) {
         m->arena = reinterpret_cast<uint8_t*>(device_arena);
     } else {
@@ -288,8 +295,8 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
         const auto& L = d.layers[l];
         launch_layernorm(mkln(m, px, flat(D), L.n1, pxn, D, R), s);
         launch_gemm(mk(m, pxn, flat(D), L.in_proj, pqkv, flat(3 * D), R), s);
-        launch_rope_rows(pqkv, 3 * D, 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
-        launch_rope_rows(pqkv, 3 * D, D, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_rope_rows(pqkv, flat(3 * D), 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_rope_rows(pqkv, flat(3 * D), D, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
         launch_kv_append(pqkv, 3 * D, D, d.heads, d.hd, d_slot, d_pos, R, b.kc(l), b.vc(l), kvb, b.cap, s);
         if (l == d.n_layers - 1) break;
         AttnArgs a;
@@ -490,59 +497,93 @@ void step_core(Batch& b, int lsd) {
 
 // ------------------------------------------------------------------------------------------------
 // Mimi: Model.LatentToMimi + MimiModel.DecodeFromLatent (model.go:141-319, mimi.go:719-789)
+//
+// Every op of the decoder is causal (mimi.go:69-76,116-125,418), and every intermediate lives in a per-utterance
+// channels-last buffer that spans the whole utterance.  Decoding frames [f0, f1) is therefore just the same launches on
+// a row sub-range of each buffer: history rows (conv taps, the transposed convs' x[t-1], the 250-step attention window)
+// are read from what earlier ranges left behind.  generate() uses this to decode finished frames on a second stream
+// while the (latency-bound) AR loop is still producing later ones.
 // ------------------------------------------------------------------------------------------------
-static void mimi_decode_group(Model& m, const float* lat, int64_t lat_bstride, int B, int T, float* pcm, float* mimi_latent) {
+void mimi_setup(Model& m, MimiWs& w, int B, int T) {
     const Desc& d = m.d;
-    hipStream_t s = m.stream;
+    w.B = B; w.T = T;
     const int C = d.mimi_dim, S = d.up_stride, T1 = T * S, F = d.mimi_ffn;
-    const int P0 = d.init_k - 1;
-    const size_t f = sizeof(float);
-    // stage lengths / pads
-    int Ls[4], Ps[4];  // channels-last buffers c0, u1, u2, u3: length and history rows
-    Ls[0] = T1; Ps[0] = 1;
+    w.P0 = d.init_k - 1;
+    w.Ls[0] = T1; w.Ps[0] = 1;
     for (int j = 0; j < 3; j++) {
-        Ls[j + 1] = Ls[j] * d.strides[j];
+        w.Ls[j + 1] = w.Ls[j] * d.strides[j];
         int need_next = j < 2 ? 1 : d.final_k - 1;
-        Ps[j + 1] = std::max(d.rb_k1[j] - 1, need_next);
+        w.Ps[j + 1] = std::max(d.rb_k1[j] - 1, need_next);
     }
-    size_t n_xp = (size_t)B * (1 + T) * C;
-    size_t n_up = (size_t)B * (P0 + T1) * C;
+    size_t n_xp = (size_t)B * (1 + T) * C, n_up = (size_t)B * (w.P0 + T1) * C;
     size_t n_n1 = (size_t)B * T1 * C, n_qkv = (size_t)B * T1 * 3 * C, n_ff = (size_t)B * T1 * F;
     size_t n_c[4], n_h[3];
-    for (int j = 0; j < 4; j++) n_c[j] = (size_t)B * (Ps[j] + Ls[j]) * d.sea_ch[j];
-    for (int j = 0; j < 3; j++) n_h[j] = (size_t)B * ((d.rb_k2[j] - 1) + Ls[j + 1]) * d.sea_hidden[j];
-    size_t total = n_xp + n_up + n_n1 + n_qkv + n_n1 + n_ff + n_c[0] + n_c[1] + n_c[2] + n_c[3] + std::max(n_h[0], std::max(n_h[1], n_h[2]));
-    DevBuf& wsb = m.work(4, total * f);
-    float* xp = wsb.as<float>();
-    float* up = xp + n_xp;
-    float* n1 = up + n_up;
-    float* qkv = n1 + n_n1;
-    float* attn = qkv + n_qkv;
-    float* ffb = attn + n_n1;
-    float* cb[4];
-    cb[0] = ffb + n_ff;
-    for (int j = 1; j < 4; j++) cb[j] = cb[j - 1] + n_c[j - 1];
-    float* hb = cb[3] + n_c[3];
+    for (int j = 0; j < 4; j++) n_c[j] = (size_t)B * (w.Ps[j] + w.Ls[j]) * d.sea_ch[j];
+    for (int j = 0; j < 3; j++) n_h[j] = (size_t)B * ((d.rb_k2[j] - 1) + w.Ls[j + 1]) * d.sea_hidden[j];
+    size_t total = n_xp + n_up + n_n1 + n_qkv * d.mimi_layers + n_n1 + n_ff + n_c[0] + 2 * (n_c[1] + n_c[2] + n_c[3]) + n_h[0] + n_h[1] + n_h[2];
+    DevBuf& wsb = m.work(4, total * sizeof(float));
+    float* p = wsb.as<float>();
+    w.xp = p; p += n_xp;
+    w.up = p; p += n_up;
+    w.n1 = p; p += n_n1;
+    for (int l = 0; l < d.mimi_layers; l++) { w.qkv[l] = p; p += n_qkv; }
+    w.attn = p; p += n_n1;
+    w.ff = p; p += n_ff;
+    w.c0 = p; p += n_c[0];
+    for (int j = 0; j < 3; j++) { w.u[j] = p; p += n_c[j + 1]; w.uo[j] = p; p += n_c[j + 1]; w.h[j] = p; p += n_h[j]; }
+    w.zeroed = false;
+}
 
-    launch_projector(lat, lat_bstride, m.at<float>(d.proj_w), m.at<float>(d.proj_b), B, T, d.ldim, C, xp, s);
-    if (mimi_latent) launch_btc_to_bct(xp, 1, B, C, T, mimi_latent, s);
-    launch_zero_rows(up, (int64_t)(P0 + T1) * C, B, (int64_t)P0 * C, s);
-    launch_upsample_depthwise(xp, m.at<float>(d.up_w0), m.at<float>(d.up_w1), nullptr, B, T, C, S, up, P0, s);
+static void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
+    const Desc& d = m.d;
+    const int C = d.mimi_dim, T1 = w.Ls[0];
+    launch_zero_rows(w.xp, (int64_t)(1 + w.T) * C, w.B, C, s);
+    launch_zero_rows(w.up, (int64_t)(w.P0 + T1) * C, w.B, (int64_t)w.P0 * C, s);
+    launch_zero_rows(w.c0, (int64_t)(w.Ps[0] + w.Ls[0]) * d.sea_ch[0], w.B, (int64_t)w.Ps[0] * d.sea_ch[0], s);
+    for (int j = 0; j < 3; j++) {
+        const int cout = d.sea_ch[j + 1], hid = d.sea_hidden[j], Ph = d.rb_k2[j] - 1;
+        launch_zero_rows(w.u[j], (int64_t)(w.Ps[j + 1] + w.Ls[j + 1]) * cout, w.B, (int64_t)w.Ps[j + 1] * cout, s);
+        launch_zero_rows(w.uo[j], (int64_t)(w.Ps[j + 1] + w.Ls[j + 1]) * cout, w.B, (int64_t)w.Ps[j + 1] * cout, s);
+        if (Ph > 0) launch_zero_rows(w.h[j], (int64_t)(Ph + w.Ls[j + 1]) * hid, w.B, (int64_t)Ph * hid, s);
+    }
+    w.zeroed = true;
+}
+
+// frames [f0, f1) of every utterance; lat: device [B][*][ldim] with lat_bstride elements between utterances;
+// pcm: device [B][T * samples_per_frame]; mimi_latent (optional): [B][C][T] (whole range only)
+void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s) {
+    const Desc& d = m.d;
+    const int B = w.B, T = w.T, C = d.mimi_dim, S = d.up_stride, T1 = T * S, F = d.mimi_ffn, P0 = w.P0;
+    if (f1 <= f0) return;
+    if (!w.zeroed) mimi_zero_history(m, w, s);
+    const int nf = f1 - f0;
+    // K13: latent -> mimi projection rows 1+f0 .. 1+f1 of xp
+    launch_projector(lat, lat_bstride, m.at<float>(d.proj_w), m.at<float>(d.proj_b), B, T, f0, f1, d.ldim, C, w.xp, s);
+    if (mimi_latent) launch_btc_to_bct(w.xp, 1, B, C, T, mimi_latent, s);
+    // K14: depthwise upsample -> rows [f0*S, f1*S) of up
+    launch_upsample_depthwise(w.xp, m.at<float>(d.up_w0), m.at<float>(d.up_w1), nullptr, B, T, f0, f1, C, S, w.up, P0, s);
     // decoder transformer (mimi.go:245-441, 506-525): positions restart at 0 for every utterance, window `context`
-    const RowMap upm = seg(C, T1, (int64_t)(P0 + T1) * C);
-    float* upx = up + (size_t)P0 * C;
-    const int R = B * T1;
+    const int t0 = f0 * S, CT = nf * S, R = B * CT;
+    const int64_t up_bs = (int64_t)(P0 + T1) * C;
+    float* upx = w.up + (size_t)(P0 + t0) * C;            // chunk rows of the residual stream
+    const RowMap upm = seg(C, CT, up_bs);
+    float* n1 = w.n1;                                       // [R][C] scratch (chunk-local)
+    float* attn = w.attn;
+    float* ffb = w.ff;
     for (int l = 0; l < d.mimi_layers; l++) {
         const auto& L = d.ml[l];
+        float* qkv = w.qkv[l];                              // [B][T1][3C], persists across ranges (keys/values of earlier frames)
+        float* qkvx = qkv + (size_t)t0 * 3 * C;
+        const RowMap qm = seg(3 * C, CT, (int64_t)T1 * 3 * C);
         launch_layernorm(mkln(m, upx, upm, L.n1, n1, C, R), s);
-        launch_gemm(mk(m, n1, flat(C), L.in_proj, qkv, flat(3 * C), R), s);
-        launch_rope_rows(qkv, 3 * C, 0, d.mimi_heads, d.mimi_hd, nullptr, 0, T1, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
-        launch_rope_rows(qkv, 3 * C, C, d.mimi_heads, d.mimi_hd, nullptr, 0, T1, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_gemm(mk(m, n1, flat(C), L.in_proj, qkvx, qm, R), s);
+        launch_rope_rows(qkvx, qm, 0, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_rope_rows(qkvx, qm, C, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
         AttnArgs a;
-        a.q = qkv; a.q_ld = 3 * C; a.q_col0 = 0;
+        a.q = qkvx; a.q_ld = 3 * C; a.q_col0 = 0; a.q_rows_per_batch = CT; a.q_batch_stride = (int64_t)T1 * 3 * C;
         a.k = qkv + C; a.v = qkv + 2 * C; a.kv_bf16 = 0;
         a.k_seg_stride = (int64_t)T1 * 3 * C; a.k_head_stride = d.mimi_hd; a.k_row_stride = 3 * C;
-        a.rows_per_seg = T1;
+        a.rows_per_seg = CT; a.pos_base = t0;
         a.context = d.mimi_ctx;
         a.out = attn; a.out_ld = C;
         a.rows = R; a.heads = d.mimi_heads; a.max_keys = std::min(T1, d.mimi_ctx);
@@ -559,52 +600,56 @@ static void mimi_decode_group(Model& m, const float* lat, int64_t lat_bstride, i
         launch_gemm(g2, s);
     }
     // SEANet decoder (mimi.go:740-788): causal convs as GEMMs over contiguous channels-last windows
+    int r0 = t0, rn = CT;   // row range at the current rate
     {
         const int ch = d.sea_ch[0];
-        launch_zero_rows(cb[0], (int64_t)(Ps[0] + Ls[0]) * ch, B, (int64_t)Ps[0] * ch, s);
-        GemmArgs g = mk(m, up, seg(C, T1, (int64_t)(P0 + T1) * C), d.init_conv, cb[0] + (size_t)Ps[0] * ch,
-                        seg(ch, Ls[0], (int64_t)(Ps[0] + Ls[0]) * ch), R);
+        GemmArgs g = mk(m, w.up + (size_t)r0 * C, seg(C, rn, up_bs), d.init_conv, w.c0 + (size_t)(w.Ps[0] + r0) * ch,
+                        seg(ch, rn, (int64_t)(w.Ps[0] + w.Ls[0]) * ch), B * rn);
         g.epi = EPI_ELU;  // x = elu(initConv(x))
         launch_gemm(g, s);
     }
     for (int j = 0; j < 3; j++) {
         const int cin = d.sea_ch[j], cout = d.sea_ch[j + 1], st = d.strides[j], hid = d.sea_hidden[j];
-        const int Lin_ = Ls[j], Lout = Ls[j + 1], Pin = Ps[j], Pout = Ps[j + 1], Ph = d.rb_k2[j] - 1;
-        float* in = cb[j];
-        float* u = cb[j + 1];
-        launch_zero_rows(u, (int64_t)(Pout + Lout) * cout, B, (int64_t)Pout * cout, s);
+        const int Lin_ = w.Ls[j], Lout = w.Ls[j + 1], Pin = w.Ps[j], Pout = w.Ps[j + 1], Ph = d.rb_k2[j] - 1;
+        const float* in = j == 0 ? w.c0 : w.uo[j - 1];
+        float* u = w.u[j];
+        float* uo = w.uo[j];
+        float* hb = w.h[j];
+        const int64_t in_bs = (int64_t)(Pin + Lin_) * cin, u_bs = (int64_t)(Pout + Lout) * cout, h_bs = (int64_t)(Ph + Lout) * hid;
         // transposed conv: window [x[t-1], x[t]] starts one row before t
-        GemmArgs gu = mk(m, in + (size_t)(Pin - 1) * cin, seg(cin, Lin_, (int64_t)(Pin + Lin_) * cin), d.up[j],
-                         u + (size_t)Pout * cout, seg((int64_t)st * cout, Lin_, (int64_t)(Pout + Lout) * cout), B * Lin_);
-        gu.aop = j == 0 ? AOP_NONE : AOP_ELU;  // elu(x) precedes up2/up3; c0 was activated in the initConv epilogue
+        GemmArgs gu = mk(m, in + (size_t)(Pin - 1 + r0) * cin, seg(cin, rn, in_bs), d.up[j],
+                         u + (size_t)(Pout + (int64_t)r0 * st) * cout, seg((int64_t)st * cout, rn, u_bs), B * rn);
+        // elu(x) precedes every transposed conv: c0 was activated in the initConv epilogue, uo[j-1] in its residual epilogue
         launch_gemm(gu, s);
-        // residual block: x + conv_k1(elu(conv_k3(elu(x))))  (mimi.go:146-164)
-        if (Ph > 0) launch_zero_rows(hb, (int64_t)(Ph + Lout) * hid, B, (int64_t)Ph * hid, s);
-        GemmArgs g1 = mk(m, u + (size_t)(Pout - (d.rb_k1[j] - 1)) * cout, seg(cout, Lout, (int64_t)(Pout + Lout) * cout), d.rb1[j],
-                         hb + (size_t)Ph * hid, seg(hid, Lout, (int64_t)(Ph + Lout) * hid), B * Lout);
+        r0 *= st; rn *= st;
+        // residual block: x + conv_k1(elu(conv_k3(elu(x))))  (mimi.go:146-164); x stays in u, elu(sum) goes to uo -- the
+        // only readers of the sum are the next transposed conv and the final conv, both behind an ELU (mimi.go:752-783)
+        GemmArgs g1 = mk(m, u + (size_t)(Pout - (d.rb_k1[j] - 1) + r0) * cout, seg(cout, rn, u_bs), d.rb1[j],
+                         hb + (size_t)(Ph + r0) * hid, seg(hid, rn, h_bs), B * rn);
         g1.aop = AOP_ELU; g1.epi = EPI_ELU;
         launch_gemm(g1, s);
-        GemmArgs g2 = mk(m, hb, seg(hid, Lout, (int64_t)(Ph + Lout) * hid), d.rb2[j], u + (size_t)Pout * cout,
-                         seg(cout, Lout, (int64_t)(Pout + Lout) * cout), B * Lout);
-        g2.R = u + (size_t)Pout * cout; g2.epi = EPI_RESADD;
+        GemmArgs g2 = mk(m, hb + (size_t)r0 * hid, seg(hid, rn, h_bs), d.rb2[j], uo + (size_t)(Pout + r0) * cout, seg(cout, rn, u_bs), B * rn);
+        g2.R = u + (size_t)(Pout + r0) * cout; g2.epi = EPI_RESADD_ELU;
         launch_gemm(g2, s);
     }
-    launch_conv_final(cb[3], Ps[3], m.at<float>(d.final_w), m.at<float>(d.final_b), B, Ls[3], d.sea_ch[3], d.final_k, pcm, s);
+    launch_conv_final(w.uo[2], w.Ps[3], m.at<float>(d.final_w), m.at<float>(d.final_b), B, w.Ls[3], r0, r0 + rn, d.sea_ch[3], d.final_k, 0, pcm, s);
 }
 
 void mimi_decode(Model& m, const float* lat, int64_t lat_bstride, int B, int T, float* pcm, float* mimi_latent) {
     if (B <= 0 || T <= 0) return;
     if ((int64_t)T * m.d.up_stride > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)T * m.d.up_stride));
-    // bound the workspace: ~1.7 MB of f32 activations per latent frame at the reference shapes
+    // bound the workspace: ~2.7 MB of f32 activations per latent frame at the reference shapes
     const Desc& d = m.d;
-    double per_frame = 4.0 * ((double)d.up_stride * (d.mimi_dim * 6.0 + d.mimi_ffn) +
-                              (double)d.samples_per_frame * (d.sea_ch[3] * 1.6 + d.sea_ch[2] * 0.5 + d.sea_ch[1] * 0.2));
-    int group = (int)std::max(1.0, std::min((double)B, 24e9 / (per_frame * T)));
+    double per_frame = 4.0 * ((double)d.up_stride * (d.mimi_dim * (4.0 + 3.0 * d.mimi_layers) + d.mimi_ffn) +
+                              (double)d.samples_per_frame * (d.sea_ch[3] * 2.6 + d.sea_ch[2] * 0.7 + d.sea_ch[1] * 0.25));
+    int group = (int)std::max(1.0, std::min((double)B, 40e9 / (per_frame * T)));
     const int64_t spu = (int64_t)T * d.samples_per_frame;
     for (int b0 = 0; b0 < B; b0 += group) {
         int nb = std::min(group, B - b0);
-        mimi_decode_group(m, lat + (int64_t)b0 * lat_bstride, lat_bstride, nb, T, pcm + (int64_t)b0 * spu,
-                          mimi_latent ? mimi_latent + (int64_t)b0 * d.mimi_dim * T : nullptr);
+        MimiWs w;
+        mimi_setup(m, w, nb, T);
+        mimi_range(m, w, lat + (int64_t)b0 * lat_bstride, lat_bstride, 0, T, pcm + (int64_t)b0 * spu,
+                   mimi_latent ? mimi_latent + (int64_t)b0 * d.mimi_dim * T : nullptr, m.stream);
     }
 }
 
@@ -737,6 +782,29 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     }
     std::vector<char> cancelled((size_t)B, 0);
     std::vector<int32_t> act((size_t)B, 1);
+    // Mimi decode of finished frame ranges runs on a second stream while the AR loop keeps stepping: the loop is a chain
+    // of latency-bound launches that leaves most of the chip idle, the decoder is throughput work, and every decoder op is
+    // causal, so frames [f0, f1) can be decoded as soon as step f1-1 has finished.
+    const int64_t spf = d.samples_per_frame;
+    const int T = ms_max;
+    if ((int64_t)T * d.up_stride > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)T * d.up_stride));
+    MimiWs mw;
+    mimi_setup(m, mw, B, T);
+    DevBuf& pcm = m.work(7, (size_t)B * T * spf * sizeof(float));
+    const char* env_chunk = getenv("PTTS_MIMI_CHUNK");
+    const int chunk = env_chunk && atoi(env_chunk) > 0 ? atoi(env_chunk) : 1 << 30;   // default: decode after the loop (measured: overlapping
+                                                                                      // slows the AR launches by as much as it hides)
+    int f_done = 0, steps_run = 0;
+    size_t ev_used = 0;
+    auto decode_upto = [&](int f1) {
+        if (f1 <= f_done) return;
+        if (m.events.size() <= ev_used) { hipEvent_t e; PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.events.push_back(e); }
+        hipEvent_t e = m.events[ev_used++];
+        PTTS_HIP(hipEventRecord(e, s));
+        PTTS_HIP(hipStreamWaitEvent(m.stream2, e, 0));
+        mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2);
+        f_done = f1;
+    };
     for (int step = 0; step < ms_max; step++) {
         int n_cancel = 0;
         for (int i = 0; i < B; i++) {  // ctx.Err() check before every step (:156-159)
@@ -746,6 +814,8 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         }
         if (n_cancel == B) break;
         enqueue_step(b, lsd, use_graph);
+        steps_run = step + 1;
+        if (steps_run % chunk == 0) decode_upto(steps_run);
         if (any_cb) {  // StepCallback runs synchronously after the step (:194-196)
             std::vector<int32_t> before = act, broke((size_t)B);
             d2h(act.data(), b.st.active, (size_t)B * 4, s);
@@ -766,14 +836,11 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     std::vector<int32_t> nf((size_t)B), es((size_t)B);
     d2h(nf.data(), b.st.n_frames, (size_t)B * 4, s);
     d2h(es.data(), b.st.eos_step, (size_t)B * 4, s);
-    int T = 0;
-    for (int i = 0; i < B; i++) if (!cancelled[i]) T = std::max(T, nf[i]);
-    const int64_t spf = d.samples_per_frame;
-    if (T > 0) {
-        DevBuf& pcm = m.work(7, (size_t)B * T * spf * sizeof(float));
-        // all decoder ops are causal, so decoding every utterance to the longest length and truncating is exact
-        mimi_decode(m, b.latents.as<float>(), (int64_t)b.max_steps * ld, B, T, pcm.as<float>(), nullptr);
-        PTTS_HIP(hipStreamSynchronize(s));
+    int Tmax = 0;
+    for (int i = 0; i < B; i++) if (!cancelled[i]) Tmax = std::max(Tmax, nf[i]);
+    if (Tmax > 0) {
+        decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
+        PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int i = 0; i < B; i++) {
             ptts_result& r = res[idx[i]];
             if (cancelled[i]) { fail_req(r, PTTS_ECANCELLED); continue; }
@@ -791,6 +858,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             r.status = PTTS_OK;
         }
     } else {
+        PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int i = 0; i < B; i++) fail_req(res[idx[i]], PTTS_ECANCELLED);
     }
 }

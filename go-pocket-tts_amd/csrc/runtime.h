@@ -45,7 +45,9 @@ struct Model {
     uint8_t* arena = nullptr;
     bool own_arena = false;
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // AR loop / prefill (high priority: latency-bound launches)
+    hipStream_t stream2 = nullptr;   // Mimi decode of finished frame ranges, concurrent with the AR loop
+    std::vector<hipEvent_t> events;
     std::mutex mu;
     std::map<int, std::unique_ptr<DevBuf>> tcomb;  // lsd_steps -> [n][flow_dim]: 0.5*(embed_s(i/n) + embed_t((i+1)/n))
     std::vector<std::unique_ptr<DevBuf>> ws;       // grow-only workspaces (Mimi decode, prefill)
@@ -100,6 +102,17 @@ struct Voice {
 };
 Voice* voice_create(Model& m, const float* const* caches, const int64_t* steps, const int64_t* offsets);
 void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slots);
+
+// buffers of one Mimi decode (all channels-last, spanning the whole utterance so that frame ranges can be decoded in order)
+struct MimiWs {
+    int B = 0, T = 0, P0 = 0;
+    int Ls[4] = {0, 0, 0, 0}, Ps[4] = {0, 0, 0, 0};
+    float *xp = nullptr, *up = nullptr, *n1 = nullptr, *qkv[MAX_LAYERS] = {nullptr}, *attn = nullptr, *ff = nullptr, *c0 = nullptr;
+    float *u[3] = {nullptr, nullptr, nullptr}, *uo[3] = {nullptr, nullptr, nullptr}, *h[3] = {nullptr, nullptr, nullptr};
+    bool zeroed = false;
+};
+void mimi_setup(Model& m, MimiWs& w, int B, int T);
+void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s);
 
 Model* model_open(Plan* plan, void* device_arena, int fill);
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);

@@ -190,6 +190,12 @@ int ptts_op_convtr1d_righttrim(const float* x /* [B,Cin,L] */, const float* w /*
                  float* y /* [B,Cout,L*stride] */);                                                                                  /* ops.ConvTranspose1DRightTrim convtranspose1d.go:213 (k = 2*stride, trim k-stride; groups 1 or Cin) */
 
 /* build/version string, e.g. "ptts-hip 0.1 gfx950" */
+/* Kernel micro-benchmarks (tools/microbench.py; device-resident synthetic operands, HIP-event timing; not part of the
+ * drop-in path).  ptts_debug_gemm also returns max |C_variant - C_other| between the two many-row GEMM kernels. */
+int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, int32_t iters, float* avg_us);
+int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
+                    float* maxdiff);
+
 const char* ptts_version(void);
 
 #ifdef __cplusplus
