@@ -468,6 +468,10 @@ int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int3
         GemmArgs g;
         g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
         g.W = dW.p; g.w_bf16 = w_bf16; g.ldw = K;
+        const size_t wt_bytes = (size_t)((N + 15) / 16) * ((K + 127) / 128) * 16 * 128 * (w_bf16 ? 2 : 4);
+        Tmp dWt(wt_bytes);
+        PTTS_HIP(hipMemset(dWt.p, 0x3c, wt_bytes));
+        g.Wt = dWt.p;
         g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
         g.M = M; g.N = N; g.K = K;
         SkinnyFuse fu;
@@ -485,6 +489,41 @@ int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int3
         PTTS_HIP(hipEventElapsedTime(&ms, e0, e1));
         *avg_us = ms * 1e3f / (float)iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    });
+}
+
+// debug: one stamped launch of the step linear (after warm-up); out receives 8 ticks per block, *n_blocks the block count
+int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, uint64_t* out, int32_t max_blocks,
+                             int32_t* n_blocks) {
+    return guard([&] {
+        require_device();
+        Tmp dA((size_t)M * K * 4), dW((size_t)N * K * 4), dC((size_t)M * N * 4 * (splitk > 1 ? splitk : 1)), dlnw((size_t)K * 4);
+        PTTS_HIP(hipMemset(dA.p, 0x3c, (size_t)M * K * 4));
+        PTTS_HIP(hipMemset(dW.p, 0x3c, (size_t)N * K * (w_bf16 ? 2 : 4)));
+        PTTS_HIP(hipMemset(dlnw.p, 0x3c, (size_t)K * 4));
+        GemmArgs g;
+        g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
+        g.W = dW.p; g.w_bf16 = w_bf16; g.ldw = K;
+        const size_t wt_bytes = (size_t)((N + 15) / 16) * ((K + 127) / 128) * 16 * 128 * (w_bf16 ? 2 : 4);
+        Tmp dWt(wt_bytes);
+        PTTS_HIP(hipMemset(dWt.p, 0x3c, wt_bytes));
+        g.Wt = dWt.p;
+        g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
+        g.M = M; g.N = N; g.K = K;
+        SkinnyFuse fu;
+        if (fuse_ln) { fu.ln = 1; fu.ln_w = dlnw.as<float>(); fu.ln_b = dlnw.as<float>(); }
+        if (!(fuse_ln ? skinny_fuse_supported(g, fu) : skinny_supported(g, splitk))) throw Error(PTTS_EINVAL, "shape not supported");
+        const int blocks = ((N + 63) / 64) * ((M + 15) / 16) * (splitk > 1 ? splitk : 1);
+        Tmp dS((size_t)blocks * 8 * 8);
+        PTTS_HIP(hipMemset(dS.p, 0, (size_t)blocks * 64));
+        for (int i = 0; i < 3; i++) launch_skinny(g, fu, splitk, dC.as<float>(), nullptr);
+        PTTS_HIP(hipDeviceSynchronize());
+        g_skinny_stamps = reinterpret_cast<unsigned long long*>(dS.p);
+        launch_skinny(g, fu, splitk, dC.as<float>(), nullptr);
+        g_skinny_stamps = nullptr;
+        PTTS_HIP(hipDeviceSynchronize());
+        *n_blocks = blocks;
+        down(out, dS.p, (size_t)std::min(blocks, max_blocks) * 64);
     });
 }
 

@@ -69,6 +69,7 @@ struct SkinnyFuse {
 bool skinny_supported(const GemmArgs& a, int splitk);
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
 void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream);
+extern unsigned long long* g_skinny_stamps;
 
 struct LnArgs {
     const float* x = nullptr; RowMap xmap;

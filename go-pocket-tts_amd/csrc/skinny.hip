@@ -52,14 +52,29 @@ union Frag8 {
     unsigned u[4];
 };
 
-template <bool WBF16>
-__global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int splitk, float* partial) {
+// prologue variants (template parameter PRO)
+constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8;
+
+template <bool WBF16, bool STAMP, int PRO, int NJ>   // NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024)
+__global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int splitk, float* partial, unsigned long long* stamps) {
+    // stamps (tools/microbench.py only; null in the product): shader-clock ticks of wave 0 of every block at the phase boundaries
+#define SK_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
+    SK_STAMP(0);
+    SK_STAMP(7);
+    // Every kernel argument is pulled into SGPRs NOW, in one batch of scalar loads.  The argument block of a fresh
+    // dispatch is cold in the scalar cache and each miss is a round trip to memory (~0.5 us); left to itself the compiler
+    // loads a field where it is first used, behind a branch on an earlier field, which chained five to six such round
+    // trips through the kernel (measured with tools/stamps_skinny.py: 2.3 us before the first weight load was issued).
+    asm volatile("" ::"s"(a.A), "s"(a.amap.ld), "s"(a.W), "s"(a.ldw), "s"(a.Wt), "s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R),
+                 "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
+    asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.pgate), "s"(fu.ldpg), "s"(fu.x_out), "s"(fu.ln),
+                 "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out));
     constexpr int WV = WBF16 ? 4 : 8;          // 16-byte weight loads per lane per super-step
     // LDS image: row r (0..15) = 2048 B = 128 chunks of 16 B; chunk c is stored at c ^ r, so the 16 lanes that read
     // the same logical chunk of 16 different rows hit 16 different bank groups
     __shared__ __attribute__((aligned(16))) unsigned char Xh[16 * 2048];
     __shared__ __attribute__((aligned(16))) unsigned char Xl[16 * 2048];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches
     const int cg = wave & 3, kq4 = wave >> 2;
     const int n = blockIdx.x * 64 + cg * 16 + (lane & 15);
     const int m0 = blockIdx.y * 16, z = blockIdx.z, q = lane >> 4;
@@ -72,106 +87,161 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
     const int ss_lo = kq4 * ssq;
 
     // ---- weights: everything this wave will multiply is requested now ----
-    uint4 w[2][WV];
-    if (a.Wt) {   // fragment-ordered copy: one contiguous 1-KiB burst per wave-instruction
+    // Fragment-ordered copy (model.cpp add_tiled, zero-padded to 16 columns x 128 k): one contiguous 1-KiB burst per
+    // wave-instruction.  The loads are unconditional (a tile / super-step that does not exist re-reads block 0 and is never
+    // multiplied or stored): a load under a condition becomes a branch, and the compiler then drains the memory pipe
+    // (s_waitcnt vmcnt(0)) between the weight loads.
+    constexpr int NTW = NJ / 2;   // super-steps per K quarter
+    uint4 w[NTW][WV];
+    {
         const int nss_all = (a.K + 127) >> 7;
         const int tile = blockIdx.x * 4 + cg, ss_base = k_begin >> 7;
         const bool tile_ok = tile * 16 < a.N;
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
+        for (int t = 0; t < NTW; t++) {
             const int ss = ss_lo + t;
-            const uint4* src = reinterpret_cast<const uint4*>(a.Wt) + (((int64_t)tile * nss_all + ss_base + ss) * WV) * 64 + lane;
+            const bool ok = tile_ok && t < ssq && ss < nss;
+            const uint4* src = reinterpret_cast<const uint4*>(a.Wt) + (ok ? (((int64_t)tile * nss_all + ss_base + ss) * WV) * 64 : 0) + lane;
 #pragma unroll
-            for (int s = 0; s < WV; s++) {
-                if (tile_ok && t < ssq && ss < nss) w[t][s] = src[s * 64];
-                else w[t][s] = make_uint4(0, 0, 0, 0);
-            }
-        }
-    } else {
-        const char* wrow = (const char*)a.W + ((int64_t)(n_ok ? n : 0) * a.ldw + k_begin) * (WBF16 ? 2 : 4);
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int kb = (ss_lo + t) * 128 + q * 32;   // this lane's 32 contiguous k of the super-step
-#pragma unroll
-            for (int s = 0; s < WV; s++) {
-                const int k = kb + s * (WBF16 ? 8 : 4);
-                if (n_ok && t < ssq && k < klen) w[t][s] = *reinterpret_cast<const uint4*>(wrow + (int64_t)k * (WBF16 ? 2 : 4));
-                else w[t][s] = make_uint4(0, 0, 0, 0);
-            }
+            for (int s = 0; s < WV; s++) w[t][s] = src[s * 64];
         }
     }
-
+    __builtin_amdgcn_sched_barrier(0);   // keep the weight requests first: the scheduler otherwise sinks them below the first wait on x
+    // ---- epilogue operands: requested now by the waves that will store (K quarter 0), consumed after the K reduction ----
+    // (an element of R that aliases C is read and written by the same lane only)
+    float e_bias = 0.f, e_addv = 0.f, e_scl = 1.f, e_r[4] = {0.f, 0.f, 0.f, 0.f}, e_g[4] = {0.f, 0.f, 0.f, 0.f};
+    if (kq4 == 0 && splitk <= 1) {
+        const int nc = n_ok ? n : 0;
+        if (a.bias) e_bias = a.bias[nc];
+        if (a.addvec) e_addv = a.addvec[nc];
+        if (a.scale) e_scl = a.scale[nc];
+        if (a.epi >= EPI_RESADD) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) e_r[reg] = a.R[(int64_t)min(m0 + q * 4 + reg, a.M - 1) * a.cmap.ld + nc];
+        }
+        if (a.epi == EPI_GATE_RESADD) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) e_g[reg] = a.gate[(int64_t)min(m0 + q * 4 + reg, a.M - 1) * a.ldg + nc];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    SK_STAMP(1);
     // ---- activations: wave w stages row w of the tile; lane owns float4 columns lane + 64 j ----
+    // Loads are unconditional with clamped indices (a row >= M replays row 0, a column >= klen replays column 0) and the
+    // value is masked afterwards; the prologue variant is a template parameter so that a launch only holds the vectors
+    // it uses (16 waves per CU leave 128 VGPRs per lane).
     {
         const int m = m0 + wave;
         const bool m_ok = m < a.M;
-        float4 xr[4];
+        const int64_t mrow = m_ok ? m : 0;
+        float4 xr[NJ];
+        int kc[NJ];
+        bool kok[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             const int k = (lane + 64 * j) * 4;
-            xr[j] = (m_ok && k < klen) ? *reinterpret_cast<const float4*>(a.A + (int64_t)m * a.amap.ld + k_begin + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            kok[j] = k < klen;
+            kc[j] = kok[j] ? k : 0;
+            xr[j] = *reinterpret_cast<const float4*>(a.A + mrow * a.amap.ld + k_begin + kc[j]);
         }
-        if (fu.partial) {   // x += gate * (sum_z partial[z] + bias); the partials are added in a fixed order
-            for (int zz = 0; zz < fu.psplit; zz++) {
+        float4 lw[(PRO & PRO_AFFINE) ? NJ : 1], lb[(PRO & PRO_AFFINE) ? NJ : 1], lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
+        auto load_params = [&]() {
+            if constexpr ((PRO & PRO_AFFINE) != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int k = (lane + 64 * j) * 4;
-                    if (m_ok && k < klen) {
-                        float4 p = *reinterpret_cast<const float4*>(fu.partial + (int64_t)zz * fu.pstride + (int64_t)m * a.K + k);
-                        if (zz == 0 && fu.pbias) { float4 b = *reinterpret_cast<const float4*>(fu.pbias + k); p.x += b.x; p.y += b.y; p.z += b.z; p.w += b.w; }
-                        if (fu.pgate) { float4 g = *reinterpret_cast<const float4*>(fu.pgate + (int64_t)m * fu.ldpg + k); p.x *= g.x; p.y *= g.y; p.z *= g.z; p.w *= g.w; }
-                        xr[j].x += p.x; xr[j].y += p.y; xr[j].z += p.z; xr[j].w += p.w;
+                for (int j = 0; j < NJ; j++) {
+                    lw[j] = *reinterpret_cast<const float4*>(fu.ln_w + kc[j]);
+                    lb[j] = *reinterpret_cast<const float4*>(fu.ln_b + kc[j]);
+                }
+            }
+            if constexpr ((PRO & PRO_MOD) != 0) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++) {
+                    lc[j] = *reinterpret_cast<const float4*>(fu.scale + mrow * fu.ldmod + kc[j]);
+                    lh[j] = *reinterpret_cast<const float4*>(fu.shift + mrow * fu.ldmod + kc[j]);
+                }
+            }
+        };
+        if constexpr ((PRO & PRO_PARTIAL) != 0) {   // x += sum_z partial[z] + bias; the partials are added in a fixed order
+            // the linear's output is summed first, then added to x, like the reference's y = W x + b; x += y
+            const float* pp = fu.partial + mrow * a.K;
+            float4 ps[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) ps[j] = *reinterpret_cast<const float4*>(pp + kc[j]);
+            __builtin_amdgcn_sched_barrier(0);
+            for (int z0 = 1; z0 < fu.psplit; z0 += 3) {   // three more slices per round trip
+                float4 p[3][NJ];
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    const int zz = min(z0 + u, fu.psplit - 1);
+#pragma unroll
+                    for (int j = 0; j < NJ; j++) p[u][j] = *reinterpret_cast<const float4*>(pp + (int64_t)zz * fu.pstride + kc[j]);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; u++) {
+                    if (z0 + u < fu.psplit) {
+#pragma unroll
+                        for (int j = 0; j < NJ; j++) { ps[j].x += p[u][j].x; ps[j].y += p[u][j].y; ps[j].z += p[u][j].z; ps[j].w += p[u][j].w; }
                     }
                 }
             }
-            if (fu.x_out && blockIdx.x == 0 && m_ok) {
+            load_params();   // after the partials: the register file (128 per lane at 16 waves) does not hold both sets in flight
+            if (fu.pbias) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const int k = (lane + 64 * j) * 4;
-                    if (k < klen) *reinterpret_cast<float4*>(fu.x_out + (int64_t)m * a.K + k) = xr[j];
+                for (int j = 0; j < NJ; j++) {
+                    const float4 p = *reinterpret_cast<const float4*>(fu.pbias + kc[j]);
+                    ps[j].x += p.x; ps[j].y += p.y; ps[j].z += p.z; ps[j].w += p.w;
                 }
             }
-        }
-        if (fu.ln) {   // LayerNorm over the full row (K == row width), biased variance (linear.go:295-309)
-            // the affine / modulation vectors are requested before the reductions, so their latency hides under them
-            float4 lw[4], lb[4], lc[4], lh[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int k = (lane + 64 * j) * 4;
-                const bool ok = k < klen;
-                lw[j] = (ok && fu.ln_w) ? *reinterpret_cast<const float4*>(fu.ln_w + k) : make_float4(1.f, 1.f, 1.f, 1.f);
-                lb[j] = (ok && fu.ln_b) ? *reinterpret_cast<const float4*>(fu.ln_b + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                lc[j] = (ok && fu.scale && m_ok) ? *reinterpret_cast<const float4*>(fu.scale + (int64_t)m * fu.ldmod + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                lh[j] = (ok && fu.scale && m_ok) ? *reinterpret_cast<const float4*>(fu.shift + (int64_t)m * fu.ldmod + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < NJ; j++) {
+                if (m_ok && kok[j]) { xr[j].x += ps[j].x; xr[j].y += ps[j].y; xr[j].z += ps[j].z; xr[j].w += ps[j].w; }
+                else xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+            if (fu.x_out && blockIdx.x == 0 && m_ok) {
+#pragma unroll
+                for (int j = 0; j < NJ; j++)
+                    if (kok[j]) *reinterpret_cast<float4*>(fu.x_out + (int64_t)m * a.K + (lane + 64 * j) * 4) = xr[j];
+            }
+        } else {
+            load_params();
+            __builtin_amdgcn_sched_barrier(0);   // every request of the prologue is in flight before the first value is consumed
+#pragma unroll
+            for (int j = 0; j < NJ; j++)
+                if (!(m_ok && kok[j])) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if constexpr ((PRO & PRO_LN) != 0) {   // LayerNorm over the full row (K == row width), biased variance (linear.go:295-309)
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; j++) s += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
+            for (int j = 0; j < NJ; j++) s += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
             const float mean = wave_sum(s) / (float)a.K;
             float v = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if ((lane + 64 * j) * 4 < klen) {
+            for (int j = 0; j < NJ; j++) {
+                if (kok[j]) {
                     float d0 = xr[j].x - mean, d1 = xr[j].y - mean, d2 = xr[j].z - mean, d3 = xr[j].w - mean;
                     v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 }
             }
             const float inv_std = 1.0f / sqrtf(wave_sum(v) / (float)a.K + fu.eps);
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int k = (lane + 64 * j) * 4;
-                if (k >= klen) continue;
+            for (int j = 0; j < NJ; j++) {
                 float4 o;
-                o.x = ((xr[j].x - mean) * inv_std * lw[j].x + lb[j].x) * (lc[j].x + 1.0f) + lh[j].x;
-                o.y = ((xr[j].y - mean) * inv_std * lw[j].y + lb[j].y) * (lc[j].y + 1.0f) + lh[j].y;
-                o.z = ((xr[j].z - mean) * inv_std * lw[j].z + lb[j].z) * (lc[j].z + 1.0f) + lh[j].z;
-                o.w = ((xr[j].w - mean) * inv_std * lw[j].w + lb[j].w) * (lc[j].w + 1.0f) + lh[j].w;
+                o.x = (xr[j].x - mean) * inv_std; o.y = (xr[j].y - mean) * inv_std; o.z = (xr[j].z - mean) * inv_std; o.w = (xr[j].w - mean) * inv_std;
+                if constexpr ((PRO & PRO_AFFINE) != 0) {
+                    o.x = o.x * lw[j].x + lb[j].x; o.y = o.y * lw[j].y + lb[j].y; o.z = o.z * lw[j].z + lb[j].z; o.w = o.w * lw[j].w + lb[j].w;
+                }
+                if constexpr ((PRO & PRO_MOD) != 0) {
+                    o.x = o.x * (lc[j].x + 1.0f) + lh[j].x; o.y = o.y * (lc[j].y + 1.0f) + lh[j].y;
+                    o.z = o.z * (lc[j].z + 1.0f) + lh[j].z; o.w = o.w * (lc[j].w + 1.0f) + lh[j].w;
+                }
+                if (!kok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
                 xr[j] = o;
-                if (fu.y_out && blockIdx.x == 0 && m_ok) *reinterpret_cast<float4*>(fu.y_out + (int64_t)m * a.K + k) = o;
+                if (fu.y_out && blockIdx.x == 0 && m_ok && kok[j]) *reinterpret_cast<float4*>(fu.y_out + (int64_t)m * a.K + (lane + 64 * j) * 4) = o;
             }
         }
+        SK_STAMP(2);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < NJ; j++) {
             const int k = (lane + 64 * j) * 4;
             if (k >= nss * 128) continue;
             unsigned h01, l01, h23, l23;
@@ -183,11 +253,12 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
         }
     }
     __syncthreads();
+    SK_STAMP(3);
 
     f32x4 acc_h = {0.f, 0.f, 0.f, 0.f}, acc_l = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15;
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
+    for (int t = 0; t < NTW; t++) {
         if (t >= ssq || ss_lo + t >= nss) break;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -215,11 +286,14 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
         }
     }
     // ---- sum the four K quarters of each column group (fixed order), reusing the activation image ----
+    if (STAMP) { if (acc_h[0] == 1.2345e-30f) SK_STAMP(6); }   // (stamp build) make stamp 4 wait for the MFMA results
+    SK_STAMP(4);
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(Xh);   // [kq4][cg][lane]
     const f32x4 accv = acc_h + acc_l;
     if (kq4 > 0) red[(kq4 * 4 + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
     __syncthreads();
+    SK_STAMP(5);
     if (kq4 > 0 || !n_ok) return;
     float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
 #pragma unroll
@@ -236,47 +310,76 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
         }
         return;
     }
-    const float bias = a.bias ? a.bias[n] : 0.0f;
-    const float addv = a.addvec ? a.addvec[n] : 0.0f;
-    const float scl = a.scale ? a.scale[n] : 1.0f;
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         int m = m0 + q * 4 + reg;
         if (m >= a.M) continue;
-        float v = acc[reg] + bias;
+        float v = acc[reg] + e_bias;
         int64_t co = (int64_t)m * a.cmap.ld + n;
         switch (a.epi) {
             case EPI_NONE: break;
             case EPI_GELU: v = gelu1(v); break;
-            case EPI_SILU: v = silu1(addv + v); break;
+            case EPI_SILU: v = silu1(e_addv + v); break;
             case EPI_ELU: v = elu1(v); break;
-            case EPI_RESADD: v = a.R[co] + v; break;
-            case EPI_SCALE_RESADD: v = a.R[co] + scl * v; break;
-            case EPI_GATE_RESADD: v = a.R[co] + a.gate[(int64_t)m * a.ldg + n] * v; break;
-            case EPI_AXPY: v = a.R[co] + a.alpha * v; break;
+            case EPI_RESADD: v = e_r[reg] + v; break;
+            case EPI_SCALE_RESADD: v = e_r[reg] + e_scl * v; break;
+            case EPI_GATE_RESADD: v = e_r[reg] + e_g[reg] * v; break;
+            case EPI_AXPY: v = e_r[reg] + a.alpha * v; break;
+            case EPI_RESADD_ELU: v = elu1(e_r[reg] + v); break;
         }
         a.C[co] = v;
     }
+    if (STAMP) { __builtin_amdgcn_s_waitcnt(0); SK_STAMP(6); }
+#undef SK_STAMP
 }
 
 bool skinny_supported(const GemmArgs& a, int splitk) {
     if (splitk < 1) splitk = 1;
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    return a.M <= 64 && a.K % 8 == 0 && kslice <= SK_KMAX && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
+    return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= SK_KMAX && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
            a.amap.ld % 4 == 0 && aligned16(a.A) && aligned16(a.W) && a.ldw % 8 == 0 && a.aop == AOP_NONE;
 }
 
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
     // the fused prologue needs whole rows in one block: K is the row width, one K slice, dense rows
     return skinny_supported(a, 1) && a.K <= SK_KMAX && a.amap.ld == a.K && a.K % 4 == 0 && (!f.scale || f.ldmod % 4 == 0) &&
-           (!f.pgate || f.ldpg % 4 == 0);
+           !f.pgate && (!f.ln_w == !f.ln_b) && (!f.partial || f.psplit >= 1) && (f.ln || !(f.ln_w || f.scale));
+}
+
+unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_stamps)
+
+template <bool WBF16, int PRO, int NJ>
+static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
+    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ>), grid, dim3(1024), 0, stream, a, fu, splitk, partial, g_skinny_stamps);
+    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ>), grid, dim3(1024), 0, stream, a, fu, splitk, partial, nullptr);
+}
+
+template <bool WBF16, int PRO>
+static void launch_pro(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
+    const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
+    if (kslice <= 512) launch_nj<WBF16, PRO, 2>(a, fu, splitk, partial, grid, stream);
+    else launch_nj<WBF16, PRO, 4>(a, fu, splitk, partial, grid, stream);
+}
+
+template <bool WBF16>
+static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
+    const int pro = (fu.ln ? PRO_LN : 0) | ((fu.ln && fu.ln_w) ? PRO_AFFINE : 0) | ((fu.ln && fu.scale) ? PRO_MOD : 0) | (fu.partial ? PRO_PARTIAL : 0);
+    switch (pro) {
+        case 0: launch_pro<WBF16, 0>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_LN | PRO_AFFINE: launch_pro<WBF16, PRO_LN | PRO_AFFINE>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_LN | PRO_AFFINE | PRO_PARTIAL: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_LN | PRO_AFFINE | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_LN | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_LN: launch_pro<WBF16, PRO_LN>(a, fu, splitk, partial, grid, stream); break;
+        default: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_MOD | PRO_PARTIAL>(a, fu, splitk, partial, grid, stream); break;
+    }
 }
 
 void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return;
     dim3 grid((a.N + 63) / 64, (a.M + 15) / 16, splitk);
-    if (a.w_bf16) hipLaunchKernelGGL(k_skinny<true>, grid, dim3(1024), 0, stream, a, fu, splitk, partial);
-    else hipLaunchKernelGGL(k_skinny<false>, grid, dim3(1024), 0, stream, a, fu, splitk, partial);
+    if (a.w_bf16) launch_w<true>(a, fu, splitk, partial, grid, stream);
+    else launch_w<false>(a, fu, splitk, partial, grid, stream);
 }
 
 }  // namespace ptts

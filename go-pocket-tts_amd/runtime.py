@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
     "ptts_decode_latents", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
-    "ptts_debug_time_skinny", "ptts_debug_gemm",
+    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host",
 ]
 

@@ -193,6 +193,8 @@ int ptts_op_convtr1d_righttrim(const float* x /* [B,Cin,L] */, const float* w /*
 /* Kernel micro-benchmarks (tools/microbench.py; device-resident synthetic operands, HIP-event timing; not part of the
  * drop-in path).  ptts_debug_gemm also returns max |C_variant - C_other| between the two many-row GEMM kernels. */
 int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, int32_t iters, float* avg_us);
+int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, uint64_t* out /* [max_blocks][8] */,
+                             int32_t max_blocks, int32_t* n_blocks);
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
 
