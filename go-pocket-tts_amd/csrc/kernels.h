@@ -173,11 +173,8 @@ struct StepState {
     int32_t* broke;         // [B] 1 when the loop left through the countdown `break` (no StepCallback for that step)
 };
 // prepares the step input: in32[b] = step==0 ? bos : latents[b][step-1] with NaN -> bos
-void launch_step_input(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, int ldim, int b,
-                       float* in32, hipStream_t stream);
-// x0[b] = noise ? noise[b][step] : 0
-void launch_step_noise(const StepState& s, const float* noise, int64_t noise_stride, int ldim, int b, float* x0,
-                       hipStream_t stream);
+void launch_step_begin(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
+                       int ldim, int b, float* in32, float* x0, hipStream_t stream);
 // stores the decoded frame, applies EOS logic, advances kv_len/step
 void launch_step_finish(const StepState& s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,
                         int64_t lat_stride, hipStream_t stream);

@@ -620,28 +620,22 @@ void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipSt
 // ------------------------------------------------------------------------------------------------
 // AR-step bookkeeping: the per-utterance loop state of runtime_native_safetensors.go:150-201 on device
 // ------------------------------------------------------------------------------------------------
-__global__ void k_step_input(StepState s, const float* latents, int64_t lat_stride, const float* bos, int ldim, int b, float* in32) {
+// One launch opens the step: the model input of every utterance (previous latent, or the BOS marker replaced by bos_emb:
+// newBOSSequenceTensor :246-253 + replaceNaNWithVector) and the starting point of the flow (this step's noise or zeros).
+__global__ void k_step_begin(StepState s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
+                             int ldim, int b, float* in32, float* x0) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= b * ldim) return;
     int bi = i / ldim, e = i % ldim;
     int st = s.step[bi];
-    float v = st == 0 ? NAN : latents[(int64_t)bi * lat_stride + (int64_t)(st - 1) * ldim + e];  // newBOSSequenceTensor :246-253
-    in32[i] = isnan(v) ? bos[e] : v;                                                              // replaceNaNWithVector
+    float v = st == 0 ? NAN : latents[(int64_t)bi * lat_stride + (int64_t)(st - 1) * ldim + e];
+    in32[i] = isnan(v) ? bos[e] : v;
+    x0[i] = noise ? noise[(int64_t)bi * noise_stride + (int64_t)st * ldim + e] : 0.0f;
 }
-void launch_step_input(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, int ldim, int b,
-                       float* in32, hipStream_t stream) {
-    hipLaunchKernelGGL(k_step_input, dim3((b * ldim + 255) / 256), dim3(256), 0, stream, s, latents, lat_stride, bos, ldim, b, in32);
-}
-
-__global__ void k_step_noise(StepState s, const float* noise, int64_t noise_stride, int ldim, int b, float* x0) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b * ldim) return;
-    int bi = i / ldim, e = i % ldim;
-    x0[i] = noise ? noise[(int64_t)bi * noise_stride + (int64_t)s.step[bi] * ldim + e] : 0.0f;
-}
-void launch_step_noise(const StepState& s, const float* noise, int64_t noise_stride, int ldim, int b, float* x0,
-                       hipStream_t stream) {
-    hipLaunchKernelGGL(k_step_noise, dim3((b * ldim + 255) / 256), dim3(256), 0, stream, s, noise, noise_stride, ldim, b, x0);
+void launch_step_begin(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
+                       int ldim, int b, float* in32, float* x0, hipStream_t stream) {
+    hipLaunchKernelGGL(k_step_begin, dim3((b * ldim + 255) / 256), dim3(256), 0, stream, s, latents, lat_stride, bos, noise, noise_stride, ldim, b,
+                       in32, x0);
 }
 
 __global__ void k_step_finish(StepState s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,

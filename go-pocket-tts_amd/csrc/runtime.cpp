@@ -49,6 +49,7 @@ Model::~Model() {
     for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (stream2) (void)hipStreamDestroy(stream2);
+
     cached_batch.reset();
     tcomb.clear();
     ws.clear();
@@ -324,19 +325,20 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
 }
 
 // every linear of the AR step goes through here so that bench.py can time the dominant kernel with HIP events
-static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = SkinnyFuse{}, int splitk = 1, float* partial = nullptr) {
+static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = SkinnyFuse{}, int splitk = 1, float* partial = nullptr, hipStream_t st = nullptr) {
+    if (!st) st = m.stream;
     const bool fused = fu.partial || fu.ln;
     const bool sk = fused ? skinny_fuse_supported(g, fu) : skinny_supported(g, splitk);
     if (!sk && (splitk > 1 || fused)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the step kernel");
     Prof& p = m.prof;
     if (p.on) {
         while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
-        PTTS_HIP(hipEventRecord(p.ev[p.used], m.stream));
+        PTTS_HIP(hipEventRecord(p.ev[p.used], st));
     }
-    if (sk) launch_skinny(g, fu, splitk, partial, m.stream);
-    else launch_gemm(g, m.stream);
+    if (sk) launch_skinny(g, fu, splitk, partial, st);
+    else launch_gemm(g, st);
     if (p.on) {
-        PTTS_HIP(hipEventRecord(p.ev[p.used + 1], m.stream));
+        PTTS_HIP(hipEventRecord(p.ev[p.used + 1], st));
         p.used += 2;
         p.launches++;
         p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 * (1 + fu.psplit) + (double)g.M * g.N * 4 * (splitk > 1 ? splitk : 1);
@@ -369,7 +371,7 @@ struct FusedIn {
 };
 
 static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const Lin& l, float* C, int64_t ldc, int M, int epi,
-                              const float* addvec, const float* R, float alpha) {
+                              const float* addvec, const float* R, float alpha, hipStream_t st = nullptr) {
     Model& m = *b.m;
     GemmArgs g = mk(m, x, flat(l.in), l, C, flat(ldc), M);
     g.epi = epi; g.addvec = addvec; g.R = R; g.alpha = alpha;
@@ -380,7 +382,8 @@ static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const
     if (in.norm && in.affine) { fu.ln_w = m.at<float>(in.norm->w); fu.ln_b = m.at<float>(in.norm->b); }
     fu.shift = in.shift; fu.scale = in.scale; fu.ldmod = in.ldmod;
     fu.y_out = in.y_out;
-    if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu); return; }
+    if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); return; }
+    if (st && st != m.stream) throw Error(PTTS_EINVAL, "ptts-hip: internal: unfused step linear on a side stream");
     // shapes outside the fused kernel (never the reference checkpoint): separate LayerNorm launch, then the linear
     LnArgs ln;
     ln.x = x; ln.xmap = flat(l.in); ln.eps = in.eps; ln.rows = M; ln.d = l.in;
@@ -459,23 +462,45 @@ void step_core(Batch& b, int lsd) {
         }
     }
     float* last = b.last.as<float>();
-    {   // out_norm (flow_lm.go:262): standalone, its rows feed two linears and the API
-        LnArgs ln = mkln(m, x, flat(D), d.out_norm, last, D, B);
-        ln.partial = pend.partial; ln.splitk = pend.splitk; ln.pstride = pend.pstride; ln.pbias = pend.bias;
-        launch_layernorm(ln, s);
-    }
-    step_gemm(m, mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B));
-    // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
-    const float* tc = m.tcomb.at(lsd)->as<float>();
     float* sy = b.sy.as<float>();
+    const float* tc = m.tcomb.at(lsd)->as<float>();
+    // out_norm (flow_lm.go:262) feeds out_eos and the flow net's cond_embed.  Both linears carry the norm (and the pending
+    // split-K sum of the last linear2) in their prologue -- one launch fewer than a stand-alone LayerNorm (parallel graph
+    // branches were tried for these two and for input_proj: the multi-branch graph ran the step 3x slower on ROCm 7.2);
+    // cond_embed also writes the normalised rows
+    // (`last`: later Euler steps and the staged API read them).  Shapes the fused kernel does not take keep the
+    // stand-alone LayerNorm launch.
+    bool tail_fused = false;
+    {
+        FusedIn in;
+        in.pend = pend; in.norm = &d.out_norm; in.eps = d.out_norm.eps;
+        GemmArgs g1 = mk(m, x, flat(D), d.cond_embed, sy, flat(C), B), g2 = mk(m, x, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B);
+        SkinnyFuse fu;
+        fu.partial = pend.partial; fu.psplit = pend.splitk; fu.pstride = pend.pstride; fu.pbias = pend.bias;
+        fu.ln = 1; fu.eps = in.eps; fu.ln_w = m.at<float>(d.out_norm.w); fu.ln_b = m.at<float>(d.out_norm.b);
+        tail_fused = skinny_fuse_supported(g1, fu) && skinny_fuse_supported(g2, fu);
+        if (tail_fused) {
+            step_fused_linear(b, x, in, d.out_eos, b.eos.as<float>(), 1, B, EPI_NONE, nullptr, nullptr, 1.0f);
+            in.y_out = last;
+            step_fused_linear(b, x, in, d.cond_embed, sy, C, B, EPI_SILU, tc, nullptr, 1.0f);
+        } else {
+            LnArgs ln = mkln(m, x, flat(D), d.out_norm, last, D, B);
+            ln.partial = pend.partial; ln.splitk = pend.splitk; ln.pstride = pend.pstride; ln.pbias = pend.bias;
+            launch_layernorm(ln, s);
+            step_gemm(m, mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B));
+        }
+    }
+    // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
     float* ada = b.ada.as<float>();
     float* fx = b.fx.as<float>();
     float* fh2 = b.fh2.as<float>();
     float* cur = b.cur.as<float>();
     for (int i = 0; i < lsd; i++) {
-        GemmArgs gc = mk(m, last, flat(D), d.cond_embed, sy, flat(C), B);  // sy = silu(0.5*(e_s+e_t) + cond_embed(c))
-        gc.epi = EPI_SILU; gc.addvec = tc + (size_t)i * C;
-        step_gemm(m, gc);
+        if (i > 0 || !tail_fused) {
+            GemmArgs gc = mk(m, last, flat(D), d.cond_embed, sy, flat(C), B);  // sy = silu(0.5*(e_s+e_t) + cond_embed(c))
+            gc.epi = EPI_SILU; gc.addvec = tc + (size_t)i * C;
+            step_gemm(m, gc);
+        }
         step_gemm(m, mk(m, sy, flat(C), d.ada_all, ada, flat(NA), B));
         step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
         for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
@@ -671,8 +696,8 @@ static void capture_step_graph(Batch& b, int lsd) {
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    launch_step_input(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), ld, b.B, b.in32.as<float>(), m.stream);
-    launch_step_noise(b.st, b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B, b.cur.as<float>(), m.stream);
+    launch_step_begin(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B,
+                      b.in32.as<float>(), b.cur.as<float>(), m.stream);
     step_core(b, lsd);
     launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
     PTTS_HIP(hipStreamEndCapture(m.stream, &g));
@@ -691,8 +716,8 @@ static void enqueue_step(Batch& b, int lsd, bool use_graph) {
     }
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    launch_step_input(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), ld, b.B, b.in32.as<float>(), m.stream);
-    launch_step_noise(b.st, b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B, b.cur.as<float>(), m.stream);
+    launch_step_begin(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B,
+                      b.in32.as<float>(), b.cur.as<float>(), m.stream);
     step_core(b, lsd);
     launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
 }

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < NJ; j++) s += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
-            const float mean = wave_sum(s) / (float)a.K;
+            const float mean = wave_sum_dpp(s) / (float)a.K;
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
                     v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 }
             }
-            const float inv_std = 1.0f / sqrtf(wave_sum(v) / (float)a.K + fu.eps);
+            const float inv_std = 1.0f / sqrtf(wave_sum_dpp(v) / (float)a.K + fu.eps);
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 float4 o;
