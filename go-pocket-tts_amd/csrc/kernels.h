@@ -158,6 +158,22 @@ void launch_conv_final(const float* in, int in_pad_rows, const float* w /*[k*C]*
                        int c, int k, int elu_in /* 0: the producer already applied ELU */, float* out /*[B][T]*/, hipStream_t stream);   // samples [t0, t1) of every utterance
 void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipStream_t stream);
 
+// One SEANet residual block (+ optionally the final conv) as a single launch, resblock.hip.  u / uo: channels-last
+// [B][pad + L][C] with `pad` zero history rows per utterance; rows [t0, t1) of every utterance are produced.
+struct ResArgs {
+    const float* u = nullptr; int64_t u_bs = 0; int pad = 0;
+    float* uo = nullptr;                       // elu(u + block(u)), same layout as u (not written when final_conv)
+    float* pcm = nullptr; int64_t pcm_bs = 0;  // final_conv: [B][L] samples
+    const void* w1 = nullptr; const void* w1_lo = nullptr; const float* b1 = nullptr;   // conv k1 (3): fragment-ordered [H][3C]
+    const void* w2 = nullptr; const void* w2_lo = nullptr; const float* b2 = nullptr;   // conv k2 (1): fragment-ordered [C][H]
+    const float* wf = nullptr; const float* bf = nullptr;                               // final conv [kf * C] f32, bias [1]
+    int B = 0, L = 0, t0 = 0, t1 = 0;
+    int C = 0, H = 0, k1 = 0, k2 = 0, kf = 0, w_bf16 = 0, final_conv = 0;
+};
+bool resblock_supported(const ResArgs& a);
+void launch_resblock(const ResArgs& a, hipStream_t stream);
+
+
 // AR-step bookkeeping (runtime_native_safetensors.go:176-192 per slot, on device)
 struct StepState {
     int32_t* kv_len;        // [B] keys in the cache (== flowTransformerLayerState.offset)

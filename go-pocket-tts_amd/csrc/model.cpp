@@ -79,6 +79,31 @@ struct Walker {
                             else reinterpret_cast<float*>(dst)[e] = v;
                         }
     }
+    // Fragment-ordered bf16 copy for resblock.hip: [16-column tile][32-deep k step][lane][8] with lane l holding
+    // W[tile*16 + (l & 15)][step*32 + (l >> 4)*8 .. +8) -- the row operand of v_mfma_f32_16x16x32_bf16, so a wave's fragment
+    // load is one contiguous 1-KiB burst.  f32 weights get a second plane with the bf16 residual (w - hi), the same
+    // split the kernels apply to activations.
+    void add_frag16(Lin& l, const std::function<void(float*)>& fill_rowmajor) {
+        if (l.out % 16 != 0 || l.in % 32 != 0) return;
+        const size_t nt = (size_t)l.out / 16, ks = (size_t)l.in / 32, count = nt * ks * 64 * 8;
+        l.wf = reserve(count * 2);
+        if (!bf16w) l.wf_lo = reserve(count * 2);
+        if (!host) return;
+        std::vector<float> rm((size_t)l.out * l.in);
+        fill_rowmajor(rm.data());
+        uint16_t* hi = reinterpret_cast<uint16_t*>(host + l.wf);
+        uint16_t* lo = bf16w ? nullptr : reinterpret_cast<uint16_t*>(host + l.wf_lo);
+        for (size_t t = 0; t < nt; t++)
+            for (size_t s = 0; s < ks; s++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int j = 0; j < 8; j++) {
+                        const float v = rm[(t * 16 + (size_t)(lane & 15)) * l.in + s * 32 + (size_t)(lane >> 4) * 8 + j];
+                        const size_t e = ((t * ks + s) * 64 + lane) * 8 + j;
+                        const uint16_t h = f32_to_bf16_rne(v);
+                        hi[e] = h;
+                        if (lo) lo[e] = f32_to_bf16_rne(v - bf16_to_f32(h));
+                    }
+    }
     Lin step_linear(const std::string& name, bool with_bias) {
         Lin l = linear(name, with_bias);
         const std::string wn = name + ".weight";
@@ -114,7 +139,7 @@ struct Walker {
         return n;
     }
     // Conv1d [Cout, Cin, k] -> GEMM operand [Cout][kx*Cin + ic] for channels-last windows (conv1d.go:86-88)
-    Lin conv_as_gemm(const std::string& name, int* k_out, int* cin_out) {
+    Lin conv_as_gemm(const std::string& name, int* k_out, int* cin_out, bool frag16 = false) {
         Lin l;
         const std::string wn = name + ".weight";
         expect_rank(wn, 3);
@@ -123,12 +148,14 @@ struct Walker {
         *cin_out = ic;
         l.out = oc;
         l.in = ic * k;
-        l.w = add_mat((size_t)oc * ic * k, [&](float* dst) {
+        auto fill = [&](float* dst) {
             std::vector<float> w = load(wn);
             for (int o = 0; o < oc; o++)
                 for (int c = 0; c < ic; c++)
                     for (int x = 0; x < k; x++) dst[(size_t)o * ic * k + (size_t)x * ic + c] = w[((size_t)o * ic + c) * k + x];
-        }, &l.bf16);
+        };
+        l.w = add_mat((size_t)oc * ic * k, fill, &l.bf16);
+        if (frag16) add_frag16(l, fill);
         if (has(name + ".bias")) l.b = add_f32((size_t)oc, [&](float* dst) { f.decode_f32(name + ".bias", dst); });
         return l;
     }
@@ -348,8 +375,8 @@ struct Walker {
             if (cin != d.sea_ch[j]) throw Error(PTTS_EFORMAT, "native: decoder convtr input channels mismatch");
             d.sea_ch[j + 1] = cout;
             int c1 = 0, c2 = 0;
-            d.rb1[j] = conv_as_gemm(mi + "decoder.model." + std::to_string(rb_idx[j]) + ".block.1.conv", &d.rb_k1[j], &c1);
-            d.rb2[j] = conv_as_gemm(mi + "decoder.model." + std::to_string(rb_idx[j]) + ".block.3.conv", &d.rb_k2[j], &c2);
+            d.rb1[j] = conv_as_gemm(mi + "decoder.model." + std::to_string(rb_idx[j]) + ".block.1.conv", &d.rb_k1[j], &c1, true);
+            d.rb2[j] = conv_as_gemm(mi + "decoder.model." + std::to_string(rb_idx[j]) + ".block.3.conv", &d.rb_k2[j], &c2, true);
             d.sea_hidden[j] = d.rb1[j].out;
             if (c1 != cout || c2 != d.sea_hidden[j] || d.rb2[j].out != cout) throw Error(PTTS_EFORMAT, "native: SEANet residual block channel mismatch");
         }

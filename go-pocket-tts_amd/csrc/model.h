@@ -18,6 +18,7 @@ constexpr int ROPE_SEQ = 8192;  // flow_transformer.go:505, mimi.go:498
 struct Lin {   // linear.go:11-16 (also a convolution expressed as a GEMM)
     size_t w = NONE, b = NONE;
     size_t wt = NONE;   // second copy in the AR-step kernel's fragment order (skinny.hip), NONE for weights the step never streams
+    size_t wf = NONE, wf_lo = NONE;   // copy in 16x16x32 MFMA fragment order for the fused SEANet block (resblock.hip); lo plane: f32 weights only
     int in = 0, out = 0, bf16 = 0;
 };
 struct Norm {  // linear.go:184-189

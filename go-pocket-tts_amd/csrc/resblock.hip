@@ -1,0 +1,232 @@
+// resblock.hip -- one SEANet residual block of the Mimi decoder as a single kernel (mimi.go:146-164,752-783):
+//     uo = elu( u + conv_k1( elu( conv_k3( elu(u) ) + b1 ) ) + b2 )          (every reader of the sum applies ELU first)
+// and, for the last block, the model's final causal convolution C -> 1 on top of it, writing PCM.
+#include "kernels.h"
+#include "device_util.h"
+
+namespace ptts {
+
+// As three GEMM launches the last two blocks (C = 128 and 64 channels at 3.84 M and 15.36 M rows for 64 x 10 s) moved
+// u, the hidden tensor and the sum through HBM seven times over: ~26 GB per batch, the bulk of the decoder's traffic.
+// Here a block owns TR consecutive rows of one utterance, reads them ONCE, keeps everything else on chip, and writes
+// the sum (or 1/C-th of it: PCM) once:
+//   A  u tile -> ELU -> bf16 hi/lo planes in LDS (XOR-swizzled 16-byte chunks), two rows of history in front
+//   B  conv_k3 as an MFMA GEMM over the 3C-wide causal window: the window of row i is rows i-2..i of the planes, so
+//      a k step is just a row offset.  +b1, ELU, split -> hidden planes in LDS
+//   C  conv_k1 GEMM over the hidden planes; + b2 + u (re-read from L2), ELU -> global (uo), or f32 LDS tile (last block)
+//   D  (last block) final conv: 3C-long dot product per output sample from the LDS tile -> PCM
+// Weights are read from fragment-ordered copies (model.cpp add_frag16), one contiguous 1-KiB burst per wave-instruction,
+// L2-resident; products are computed transposed (weights as the MFMA row operand) so a lane ends up with four
+// consecutive channels of one row.  Numerics are those of k_gemm3 (activations hi + lo, f32 weights hi + lo,
+// f32 accumulation).  The first HALO rows of a tile only feed later rows and are recomputed by the neighbouring tile.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split2r(float a, float b, unsigned& hi, unsigned& lo) {
+    f32x2 f = {a, b};
+    bf16x2 h = __builtin_convertvector(f, bf16x2);
+    f32x2 r = f - __builtin_convertvector(h, f32x2);
+    bf16x2 l = __builtin_convertvector(r, bf16x2);
+    hi = *reinterpret_cast<unsigned*>(&h);
+    lo = *reinterpret_cast<unsigned*>(&l);
+}
+
+union FragR {
+    bf16x8 v;
+    uint4 q;
+};
+
+template <int C, int H, int NW, bool FINAL, bool WBF16>
+__global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
+    constexpr int TR = NW * 16;                       // rows per tile
+    constexpr int HALO = FINAL ? 4 : 2;               // leading rows that are only inputs to later rows
+    constexpr int TOUT = TR - HALO;
+    constexpr int NTH = NW * 64;
+    constexpr int ROWB = C * 2, HROWB = H * 2;        // bytes per plane row
+    constexpr int CM = C / 8 - 1, HM = H / 8 - 1;     // chunk-swizzle masks (16-byte chunks per row - 1)
+    constexpr int PLANE = (TR + 2) * ROWB, HPLANE = TR * HROWB;
+    constexpr int FLD = C + 1;                        // padded row of the f32 tile of stage D
+    constexpr int FTILE = FINAL ? (TR + 2) * FLD * 4 : 0;
+    constexpr int EU_BYTES = 2 * PLANE > FTILE ? 2 * PLANE : FTILE;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EU_BYTES + 2 * HPLANE];
+    unsigned char* eu_hi = smem;
+    unsigned char* eu_lo = smem + PLANE;
+    unsigned char* h_hi = smem + EU_BYTES;
+    unsigned char* h_lo = h_hi + HPLANE;
+    float* ft = reinterpret_cast<float*>(smem);       // stage D tile, aliases the eu planes (dead after stage B)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int tiles = (a.t1 - a.t0 + TOUT - 1) / TOUT;
+    const int bi = blockIdx.x / tiles, tb = a.t0 + (blockIdx.x % tiles) * TOUT;   // first output row of the tile
+    const int row0 = tb - HALO;                                                     // global row of tile row 0
+    const float* ub = a.u + (int64_t)bi * a.u_bs + (int64_t)a.pad * C;             // row 0 of the utterance
+
+    // ---- A: u -> elu -> hi/lo planes.  Rows before the utterance (beyond its zero history) or past its end are zeros ----
+    {
+        constexpr int V = TR * C / 4 / NTH;           // float4 per thread
+        float4 x[V];
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const int e = (tid + j * NTH) * 4, i = e / C, c = e % C;
+            const int gr = row0 + i;
+            const bool ok = gr >= -a.pad && gr < a.L;
+            x[j] = *reinterpret_cast<const float4*>(ub + (int64_t)(ok ? gr : 0) * C + c);
+            if (!ok) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < 2 * ROWB / 16) {                    // the two history rows in front of the tile only feed halo rows: zeros
+            reinterpret_cast<uint4*>(eu_hi)[tid] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(eu_lo)[tid] = make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const int e = (tid + j * NTH) * 4, i = e / C, c = e % C;
+            const int rho = i + 2;
+            unsigned h01, l01, h23, l23;
+            split2r(elu_fast(x[j].x), elu_fast(x[j].y), h01, l01);
+            split2r(elu_fast(x[j].z), elu_fast(x[j].w), h23, l23);
+            const int off = rho * ROWB + ((((c >> 3) ^ rho) & CM) << 4) + ((c & 4) << 1);
+            *reinterpret_cast<uint2*>(eu_hi + off) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(eu_lo + off) = make_uint2(l01, l23);
+        }
+    }
+    __syncthreads();
+
+    const int i_lane = wave * 16 + r16;               // tile row this lane owns in the MFMA operands / results
+    // ---- B: hidden = elu(conv_k3(eu) + b1) ----
+    {
+        constexpr int NT = H / 16, KS = 3 * C / 32;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4* w1 = reinterpret_cast<const uint4*>(a.w1) + lane;
+        const uint4* w1l = reinterpret_cast<const uint4*>(a.w1_lo) + lane;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int tap = (s * 32) / C, c0 = (s * 32) % C;
+            const int rho = i_lane + tap;             // window row i-2+tap, stored at rho = that + 2
+            const int off = rho * ROWB + ((((c0 >> 3) + g) ^ rho) & CM) * 16;
+            FragR xh, xl;
+            xh.q = *reinterpret_cast<const uint4*>(eu_hi + off);
+            xl.q = *reinterpret_cast<const uint4*>(eu_lo + off);
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                FragR wh;
+                wh.q = w1[(n * KS + s) * 64];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0);
+                if constexpr (!WBF16) {
+                    FragR wl;
+                    wl.q = w1l[(n * KS + s) * 64];
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc[n], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int n = 0; n < NT; n++) {                // lane: row i_lane, hidden channels n*16 + 4g .. +3
+            const int ch = n * 16 + 4 * g;
+            const float4 b = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned h01, l01, h23, l23;
+            split2r(elu_fast(acc[n][0] + b.x), elu_fast(acc[n][1] + b.y), h01, l01);
+            split2r(elu_fast(acc[n][2] + b.z), elu_fast(acc[n][3] + b.w), h23, l23);
+            const int off = i_lane * HROWB + ((((ch >> 3) ^ i_lane) & HM) << 4) + ((ch & 4) << 1);
+            *reinterpret_cast<uint2*>(h_hi + off) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(h_lo + off) = make_uint2(l01, l23);
+        }
+    }
+    __syncthreads();
+
+    // ---- C: sum = elu(u + conv_k1(hidden) + b2) ----
+    {
+        constexpr int NT = C / 16, KS = H / 32;
+        f32x4 acc[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int gr = row0 + i_lane;
+        const bool in_seq = gr >= 0 && gr < a.L;
+        // residual operand: requested before the product, consumed after it (L2-hot: this block has just read the rows)
+        float4 ur[NT];
+#pragma unroll
+        for (int n = 0; n < NT; n++) ur[n] = *reinterpret_cast<const float4*>(ub + (int64_t)(in_seq ? gr : 0) * C + n * 16 + 4 * g);
+        const uint4* w2 = reinterpret_cast<const uint4*>(a.w2) + lane;
+        const uint4* w2l = reinterpret_cast<const uint4*>(a.w2_lo) + lane;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int off = i_lane * HROWB + (((s * 4 + g) ^ i_lane) & HM) * 16;
+            FragR xh, xl;
+            xh.q = *reinterpret_cast<const uint4*>(h_hi + off);
+            xl.q = *reinterpret_cast<const uint4*>(h_lo + off);
+#pragma unroll
+            for (int n = 0; n < NT; n++) {
+                FragR wh;
+                wh.q = w2[(n * KS + s) * 64];
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc[n], 0, 0, 0);
+                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0);
+                if constexpr (!WBF16) {
+                    FragR wl;
+                    wl.q = w2l[(n * KS + s) * 64];
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc[n], 0, 0, 0);
+                }
+            }
+        }
+        const bool store = !FINAL && i_lane >= HALO && gr < a.t1 && in_seq;
+        float* orow = FINAL ? nullptr : a.uo + (int64_t)bi * a.u_bs + (int64_t)(a.pad + (in_seq ? gr : 0)) * C;
+#pragma unroll
+        for (int n = 0; n < NT; n++) {
+            const int ch = n * 16 + 4 * g;
+            const float4 b = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 v;
+            v.x = elu_fast(ur[n].x + (acc[n][0] + b.x)); v.y = elu_fast(ur[n].y + (acc[n][1] + b.y));
+            v.z = elu_fast(ur[n].z + (acc[n][2] + b.z)); v.w = elu_fast(ur[n].w + (acc[n][3] + b.w));
+            if constexpr (FINAL) {                    // rows before the utterance are the final conv's zero padding
+                if (!in_seq) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                float* d = ft + (i_lane + 2) * FLD + ch;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            } else if (store) {
+                *reinterpret_cast<float4*>(orow + ch) = v;
+            }
+        }
+    }
+    if constexpr (FINAL) {
+        // ---- D: pcm[row] = bf + sum_{tap, c} sum[row-2+tap][c] * wf[tap*C + c]; four threads per row, 3C/4 terms each ----
+        __syncthreads();
+        constexpr int QL = 3 * C / 4;
+        const int i = tid >> 2, qd = tid & 3;
+        float s = 0.0f;
+#pragma unroll 8
+        for (int k = qd * QL; k < (qd + 1) * QL; k++) s += ft[(i + k / C) * FLD + (k % C)] * a.wf[k];   // tile row i-2+tap lives at index i+tap
+        s += __shfl_xor(s, 1, WAVE);
+        s += __shfl_xor(s, 2, WAVE);
+        const int gr = row0 + i;
+        if (qd == 0 && i >= HALO && gr < a.t1 && gr < a.L) a.pcm[(int64_t)bi * a.pcm_bs + gr] = s + (a.bf ? a.bf[0] : 0.0f);
+    }
+}
+
+bool resblock_supported(const ResArgs& a) {
+    const bool dims = (a.C == 64 && a.H == 32) || (a.C == 128 && a.H == 64);
+    return dims && a.k1 == 3 && a.k2 == 1 && a.w1 && a.w2 && (a.w_bf16 || (a.w1_lo && a.w2_lo)) && a.pad >= 2 && aligned16(a.u) &&
+           (a.final_conv ? (a.kf == 3 && a.wf && a.pcm) : (a.uo != nullptr && aligned16(a.uo))) && a.u_bs % 4 == 0 && a.t1 > a.t0;
+}
+
+template <int C, int H, int NW>
+static void launch_rb(const ResArgs& a, hipStream_t stream) {
+    const int tout = NW * 16 - (a.final_conv ? 4 : 2);
+    const int tiles = (a.t1 - a.t0 + tout - 1) / tout;
+    dim3 grid((unsigned)(a.B * tiles));
+    if (a.final_conv) {
+        if (a.w_bf16) hipLaunchKernelGGL((k_resblock<C, H, NW, true, true>), grid, dim3(NW * 64), 0, stream, a);
+        else hipLaunchKernelGGL((k_resblock<C, H, NW, true, false>), grid, dim3(NW * 64), 0, stream, a);
+    } else {
+        if (a.w_bf16) hipLaunchKernelGGL((k_resblock<C, H, NW, false, true>), grid, dim3(NW * 64), 0, stream, a);
+        else hipLaunchKernelGGL((k_resblock<C, H, NW, false, false>), grid, dim3(NW * 64), 0, stream, a);
+    }
+}
+
+void launch_resblock(const ResArgs& a, hipStream_t stream) {
+    if (a.C == 64) launch_rb<64, 32, 8>(a, stream);    // 128-row tiles, ~50 KB of LDS: three blocks per CU
+    else launch_rb<128, 64, 4>(a, stream);             // 64-row tiles, same footprint
+}
+
+}  // namespace ptts

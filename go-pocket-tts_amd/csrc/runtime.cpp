@@ -633,6 +633,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         g.epi = EPI_ELU;  // x = elu(initConv(x))
         launch_gemm(g, s);
     }
+    bool final_done = false;
     for (int j = 0; j < 3; j++) {
         const int cin = d.sea_ch[j], cout = d.sea_ch[j + 1], st = d.strides[j], hid = d.sea_hidden[j];
         const int Lin_ = w.Ls[j], Lout = w.Ls[j + 1], Pin = w.Ps[j], Pout = w.Ps[j + 1], Ph = d.rb_k2[j] - 1;
@@ -648,7 +649,25 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         launch_gemm(gu, s);
         r0 *= st; rn *= st;
         // residual block: x + conv_k1(elu(conv_k3(elu(x))))  (mimi.go:146-164); x stays in u, elu(sum) goes to uo -- the
-        // only readers of the sum are the next transposed conv and the final conv, both behind an ELU (mimi.go:752-783)
+        // only readers of the sum are the next transposed conv and the final conv, both behind an ELU (mimi.go:752-783).
+        // The two narrow blocks run as one launch each (resblock.hip); the last one also applies the final conv.
+        {
+            ResArgs ra;
+            ra.u = u; ra.u_bs = u_bs; ra.pad = Pout; ra.uo = uo;
+            ra.w1 = m.at<uint8_t>(d.rb1[j].wf); ra.w1_lo = m.at<uint8_t>(d.rb1[j].wf_lo); ra.b1 = m.at<float>(d.rb1[j].b);
+            ra.w2 = m.at<uint8_t>(d.rb2[j].wf); ra.w2_lo = m.at<uint8_t>(d.rb2[j].wf_lo); ra.b2 = m.at<float>(d.rb2[j].b);
+            ra.B = B; ra.L = Lout; ra.t0 = r0; ra.t1 = r0 + rn;
+            ra.C = cout; ra.H = hid; ra.k1 = d.rb_k1[j]; ra.k2 = d.rb_k2[j]; ra.w_bf16 = d.rb1[j].bf16;
+            if (j == 2) {
+                ra.final_conv = 1; ra.kf = d.final_k; ra.wf = m.at<float>(d.final_w); ra.bf = m.at<float>(d.final_b);
+                ra.pcm = pcm; ra.pcm_bs = w.Ls[3];
+            }
+            if (d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 == d.rb2[j].bf16 && resblock_supported(ra)) {
+                launch_resblock(ra, s);
+                if (j == 2) final_done = true;
+                continue;
+            }
+        }
         GemmArgs g1 = mk(m, u + (size_t)(Pout - (d.rb_k1[j] - 1) + r0) * cout, seg(cout, rn, u_bs), d.rb1[j],
                          hb + (size_t)(Ph + r0) * hid, seg(hid, rn, h_bs), B * rn);
         g1.aop = AOP_ELU; g1.epi = EPI_ELU;
@@ -657,6 +676,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         g2.R = u + (size_t)(Pout + r0) * cout; g2.epi = EPI_RESADD_ELU;
         launch_gemm(g2, s);
     }
+    if (!final_done)
     launch_conv_final(w.uo[2], w.Ps[3], m.at<float>(d.final_w), m.at<float>(d.final_b), B, w.Ls[3], r0, r0 + rn, d.sea_ch[3], d.final_k, 0, pcm, s);
 }
 
