@@ -166,7 +166,7 @@ struct ResArgs {
     float* pcm = nullptr; int64_t pcm_bs = 0;  // final_conv: [B][L] samples
     const void* w1 = nullptr; const void* w1_lo = nullptr; const float* b1 = nullptr;   // conv k1 (3): fragment-ordered [H][3C]
     const void* w2 = nullptr; const void* w2_lo = nullptr; const float* b2 = nullptr;   // conv k2 (1): fragment-ordered [C][H]
-    const float* wf = nullptr; const float* bf = nullptr;                               // final conv [kf * C] f32, bias [1]
+    const void* wf_hi = nullptr; const void* wf_lo = nullptr; const float* bf = nullptr;  // final conv as a one-column fragment-ordered matrix (hi + lo planes), bias [1]
     int B = 0, L = 0, t0 = 0, t1 = 0;
     int C = 0, H = 0, k1 = 0, k2 = 0, kf = 0, w_bf16 = 0, final_conv = 0;
 };

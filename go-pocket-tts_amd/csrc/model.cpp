@@ -389,6 +389,25 @@ struct Walker {
             d.final_w = add_f32((size_t)ic * k, [&](float* dst) { std::vector<float> w = load(cn + ".weight"); for (int c = 0; c < ic; c++) for (int x = 0; x < k; x++) dst[(size_t)x * ic + c] = w[(size_t)c * k + x]; });
             if (has(cn + ".bias")) d.final_b = add_f32(1, [&](float* dst) { f.decode_f32(cn + ".bias", dst); });
             d.n_params += (int64_t)ic * k;
+            if ((ic * k) % 32 == 0) {   // one-column matrix in MFMA fragment order for the fused last block
+                const size_t ks = (size_t)ic * k / 32, count = ks * 64 * 8;
+                d.final_wf = reserve(count * 2);
+                d.final_wf_lo = reserve(count * 2);
+                if (host) {
+                    std::vector<float> w = load(cn + ".weight");
+                    uint16_t* hi = reinterpret_cast<uint16_t*>(host + d.final_wf);
+                    uint16_t* lo = reinterpret_cast<uint16_t*>(host + d.final_wf_lo);
+                    for (size_t s = 0; s < ks; s++)
+                        for (int lane = 0; lane < 64; lane++)
+                            for (int j = 0; j < 8; j++) {
+                                const size_t kk = s * 32 + (size_t)(lane >> 4) * 8 + j;   // = tap * ic + c
+                                const float v = (lane & 15) == 0 ? w[(kk % ic) * k + kk / ic] : 0.0f;
+                                const uint16_t h = f32_to_bf16_rne(v);
+                                hi[(s * 64 + lane) * 8 + j] = h;
+                                lo[(s * 64 + lane) * 8 + j] = f32_to_bf16_rne(v - bf16_to_f32(h));
+                            }
+                }
+            }
         }
         d.samples_per_frame = (int64_t)d.up_stride * d.strides[0] * d.strides[1] * d.strides[2];
         d.total_bytes = (cur + 255) & ~(size_t)255;

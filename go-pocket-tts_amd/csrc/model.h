@@ -50,6 +50,7 @@ struct Desc {
     int init_k = 0, rb_k1[3] = {0, 0, 0}, rb_k2[3] = {0, 0, 0}, final_k = 0;
     Lin init_conv, up[3], rb1[3], rb2[3];
     size_t final_w = NONE, final_b = NONE;
+    size_t final_wf = NONE, final_wf_lo = NONE;   // final conv as column 0 of a 16-column fragment-ordered matrix, bf16 hi + lo planes (resblock.hip)
     int64_t samples_per_frame = 0;
     int64_t n_params = 0;
     size_t total_bytes = 0;

@@ -14,7 +14,8 @@ namespace ptts {
 //   B  conv_k3 as an MFMA GEMM over the 3C-wide causal window: the window of row i is rows i-2..i of the planes, so
 //      a k step is just a row offset.  +b1, ELU, split -> hidden planes in LDS
 //   C  conv_k1 GEMM over the hidden planes; + b2 + u (re-read from L2), ELU -> global (uo), or f32 LDS tile (last block)
-//   D  (last block) final conv: 3C-long dot product per output sample from the LDS tile -> PCM
+//   D  (last block) final conv: the sum goes back into the planes and a one-column MFMA product over the same windows
+//      gives the PCM sample of every row
 // Weights are read from fragment-ordered copies (model.cpp add_frag16), one contiguous 1-KiB burst per wave-instruction,
 // L2-resident; products are computed transposed (weights as the MFMA row operand) so a lane ends up with four
 // consecutive channels of one row.  Numerics are those of k_gemm3 (activations hi + lo, f32 weights hi + lo,
@@ -47,15 +48,12 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
     constexpr int ROWB = C * 2, HROWB = H * 2;        // bytes per plane row
     constexpr int CM = C / 8 - 1, HM = H / 8 - 1;     // chunk-swizzle masks (16-byte chunks per row - 1)
     constexpr int PLANE = (TR + 2) * ROWB, HPLANE = TR * HROWB;
-    constexpr int FLD = C + 1;                        // padded row of the f32 tile of stage D
-    constexpr int FTILE = FINAL ? (TR + 2) * FLD * 4 : 0;
-    constexpr int EU_BYTES = 2 * PLANE > FTILE ? 2 * PLANE : FTILE;
+    constexpr int EU_BYTES = 2 * PLANE;
     __shared__ __attribute__((aligned(16))) unsigned char smem[EU_BYTES + 2 * HPLANE];
     unsigned char* eu_hi = smem;
     unsigned char* eu_lo = smem + PLANE;
     unsigned char* h_hi = smem + EU_BYTES;
     unsigned char* h_lo = h_hi + HPLANE;
-    float* ft = reinterpret_cast<float*>(smem);       // stage D tile, aliases the eu planes (dead after stage B)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
@@ -180,34 +178,51 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
             float4 v;
             v.x = elu_fast(ur[n].x + (acc[n][0] + b.x)); v.y = elu_fast(ur[n].y + (acc[n][1] + b.y));
             v.z = elu_fast(ur[n].z + (acc[n][2] + b.z)); v.w = elu_fast(ur[n].w + (acc[n][3] + b.w));
-            if constexpr (FINAL) {                    // rows before the utterance are the final conv's zero padding
-                if (!in_seq) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                float* d = ft + (i_lane + 2) * FLD + ch;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            if constexpr (FINAL) {                    // the sum replaces elu(u) in the planes (dead since stage B's barrier);
+                if (!in_seq) v = make_float4(0.f, 0.f, 0.f, 0.f);   // rows before the utterance are the final conv's zero padding
+                const int rho = i_lane + 2;
+                unsigned h01, l01, h23, l23;
+                split2r(v.x, v.y, h01, l01);
+                split2r(v.z, v.w, h23, l23);
+                const int off = rho * ROWB + ((((ch >> 3) ^ rho) & CM) << 4) + ((ch & 4) << 1);
+                *reinterpret_cast<uint2*>(eu_hi + off) = make_uint2(h01, h23);
+                *reinterpret_cast<uint2*>(eu_lo + off) = make_uint2(l01, l23);
             } else if (store) {
                 *reinterpret_cast<float4*>(orow + ch) = v;
             }
         }
     }
     if constexpr (FINAL) {
-        // ---- D: pcm[row] = bf + sum_{tap, c} sum[row-2+tap][c] * wf[tap*C + c]; four threads per row, 3C/4 terms each ----
+        // ---- D: pcm[row] = bf + sum_{tap, c} sum[row-2+tap][c] * wf[tap*C + c]: the same windowed product as stage B with a
+        // one-column weight matrix (column 0 of a 16-column fragment; f32 weights, so hi and lo planes) ----
         __syncthreads();
-        constexpr int QL = 3 * C / 4;
-        const int i = tid >> 2, qd = tid & 3;
-        float s = 0.0f;
-#pragma unroll 8
-        for (int k = qd * QL; k < (qd + 1) * QL; k++) s += ft[(i + k / C) * FLD + (k % C)] * a.wf[k];   // tile row i-2+tap lives at index i+tap
-        s += __shfl_xor(s, 1, WAVE);
-        s += __shfl_xor(s, 2, WAVE);
-        const int gr = row0 + i;
-        if (qd == 0 && i >= HALO && gr < a.t1 && gr < a.L) a.pcm[(int64_t)bi * a.pcm_bs + gr] = s + (a.bf ? a.bf[0] : 0.0f);
+        constexpr int KS = 3 * C / 32;
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint4* wfh = reinterpret_cast<const uint4*>(a.wf_hi) + lane;
+        const uint4* wfl = reinterpret_cast<const uint4*>(a.wf_lo) + lane;
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+            const int tap = (s * 32) / C, c0 = (s * 32) % C;
+            const int rho = i_lane + tap;
+            const int off = rho * ROWB + ((((c0 >> 3) + g) ^ rho) & CM) * 16;
+            FragR xh, xl, wh, wl;
+            xh.q = *reinterpret_cast<const uint4*>(eu_hi + off);
+            xl.q = *reinterpret_cast<const uint4*>(eu_lo + off);
+            wh.q = wfh[s * 64];
+            wl.q = wfl[s * 64];
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc, 0, 0, 0);
+        }
+        const int gr = row0 + i_lane;                 // result column 0 sits in register 0 of lane group 0
+        if (g == 0 && i_lane >= HALO && gr < a.t1 && gr < a.L) a.pcm[(int64_t)bi * a.pcm_bs + gr] = acc[0] + (a.bf ? a.bf[0] : 0.0f);
     }
 }
 
 bool resblock_supported(const ResArgs& a) {
     const bool dims = (a.C == 64 && a.H == 32) || (a.C == 128 && a.H == 64);
     return dims && a.k1 == 3 && a.k2 == 1 && a.w1 && a.w2 && (a.w_bf16 || (a.w1_lo && a.w2_lo)) && a.pad >= 2 && aligned16(a.u) &&
-           (a.final_conv ? (a.kf == 3 && a.wf && a.pcm) : (a.uo != nullptr && aligned16(a.uo))) && a.u_bs % 4 == 0 && a.t1 > a.t0;
+           (a.final_conv ? (a.kf == 3 && a.wf_hi && a.wf_lo && a.pcm) : (a.uo != nullptr && aligned16(a.uo))) && a.u_bs % 4 == 0 && a.t1 > a.t0;
 }
 
 template <int C, int H, int NW>

@@ -659,7 +659,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
             ra.B = B; ra.L = Lout; ra.t0 = r0; ra.t1 = r0 + rn;
             ra.C = cout; ra.H = hid; ra.k1 = d.rb_k1[j]; ra.k2 = d.rb_k2[j]; ra.w_bf16 = d.rb1[j].bf16;
             if (j == 2) {
-                ra.final_conv = 1; ra.kf = d.final_k; ra.wf = m.at<float>(d.final_w); ra.bf = m.at<float>(d.final_b);
+                ra.final_conv = 1; ra.kf = d.final_k; ra.wf_hi = m.at<uint8_t>(d.final_wf); ra.wf_lo = m.at<uint8_t>(d.final_wf_lo); ra.bf = m.at<float>(d.final_b);
                 ra.pcm = pcm; ra.pcm_bs = w.Ls[3];
             }
             if (d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 == d.rb2[j].bf16 && resblock_supported(ra)) {
