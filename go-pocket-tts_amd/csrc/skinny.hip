@@ -56,19 +56,15 @@ union Frag8 {
 constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8;
 
 template <bool WBF16, bool STAMP, int PRO, int NJ>   // NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024)
-__global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int splitk, float* partial, unsigned long long* stamps) {
+__global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_m, int p_n, int p_k, int splitk, GemmArgs a, SkinnyFuse fu,
+                                                 float* partial, unsigned long long* stamps) {
+    // The seven leading scalars (copies of a.Wt, a.A, a.amap.ld, a.M, a.N, a.K, and the split) are what the weight and
+    // activation requests need.  They are built with -amdgpu-kernarg-preload-count: the dispatcher delivers them in SGPRs,
+    // so those requests leave before the first scalar-cache round trip for the argument block has returned.
     // stamps (tools/microbench.py only; null in the product): shader-clock ticks of wave 0 of every block at the phase boundaries
 #define SK_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
     SK_STAMP(7);
-    // Every kernel argument is pulled into SGPRs NOW, in one batch of scalar loads.  The argument block of a fresh
-    // dispatch is cold in the scalar cache and each miss is a round trip to memory (~0.5 us); left to itself the compiler
-    // loads a field where it is first used, behind a branch on an earlier field, which chained five to six such round
-    // trips through the kernel (measured with tools/stamps_skinny.py: 2.3 us before the first weight load was issued).
-    asm volatile("" ::"s"(a.A), "s"(a.amap.ld), "s"(a.W), "s"(a.ldw), "s"(a.Wt), "s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R),
-                 "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
-    asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.pgate), "s"(fu.ldpg), "s"(fu.x_out), "s"(fu.ln),
-                 "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out));
     constexpr int WV = WBF16 ? 4 : 8;          // 16-byte weight loads per lane per super-step
     // LDS image: row r (0..15) = 2048 B = 128 chunks of 16 B; chunk c is stored at c ^ r, so the 16 lanes that read
     // the same logical chunk of 16 different rows hit 16 different bank groups
@@ -78,9 +74,9 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
     const int cg = wave & 3, kq4 = wave >> 2;
     const int n = blockIdx.x * 64 + cg * 16 + (lane & 15);
     const int m0 = blockIdx.y * 16, z = blockIdx.z, q = lane >> 4;
-    const bool n_ok = n < a.N;
-    const int kper = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    const int k_begin = z * kper, k_end = min(a.K, k_begin + kper);
+    const bool n_ok = n < p_n;
+    const int kper = splitk > 1 ? ((p_k + splitk - 1) / splitk + 127) / 128 * 128 : p_k;
+    const int k_begin = z * kper, k_end = min(p_k, k_begin + kper);
     const int klen = k_end - k_begin;          // <= SK_KMAX (host guarantees)
     const int nss = (klen + 127) >> 7;         // 128-deep super-steps in the slice (<= 8)
     const int ssq = (nss + 3) >> 2;            // super-steps per K quarter (<= 2)
@@ -94,14 +90,14 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
     constexpr int NTW = NJ / 2;   // super-steps per K quarter
     uint4 w[NTW][WV];
     {
-        const int nss_all = (a.K + 127) >> 7;
+        const int nss_all = (p_k + 127) >> 7;
         const int tile = blockIdx.x * 4 + cg, ss_base = k_begin >> 7;
-        const bool tile_ok = tile * 16 < a.N;
+        const bool tile_ok = tile * 16 < p_n;
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
             const int ss = ss_lo + t;
             const bool ok = tile_ok && t < ssq && ss < nss;
-            const uint4* src = reinterpret_cast<const uint4*>(a.Wt) + (ok ? (((int64_t)tile * nss_all + ss_base + ss) * WV) * 64 : 0) + lane;
+            const uint4* src = reinterpret_cast<const uint4*>(p_wt) + (ok ? (((int64_t)tile * nss_all + ss_base + ss) * WV) * 64 : 0) + lane;
 #pragma unroll
             for (int s = 0; s < WV; s++) w[t][s] = src[s * 64];
         }
@@ -117,11 +113,11 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
         if (a.scale) e_scl = a.scale[nc];
         if (a.epi >= EPI_RESADD) {
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) e_r[reg] = a.R[(int64_t)min(m0 + q * 4 + reg, a.M - 1) * a.cmap.ld + nc];
+            for (int reg = 0; reg < 4; reg++) e_r[reg] = a.R[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.cmap.ld + nc];
         }
         if (a.epi == EPI_GATE_RESADD) {
 #pragma unroll
-            for (int reg = 0; reg < 4; reg++) e_g[reg] = a.gate[(int64_t)min(m0 + q * 4 + reg, a.M - 1) * a.ldg + nc];
+            for (int reg = 0; reg < 4; reg++) e_g[reg] = a.gate[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.ldg + nc];
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -132,7 +128,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
     // it uses (16 waves per CU leave 128 VGPRs per lane).
     {
         const int m = m0 + wave;
-        const bool m_ok = m < a.M;
+        const bool m_ok = m < p_m;
         const int64_t mrow = m_ok ? m : 0;
         float4 xr[NJ];
         int kc[NJ];
@@ -142,8 +138,16 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
             const int k = (lane + 64 * j) * 4;
             kok[j] = k < klen;
             kc[j] = kok[j] ? k : 0;
-            xr[j] = *reinterpret_cast<const float4*>(a.A + mrow * a.amap.ld + k_begin + kc[j]);
+            xr[j] = *reinterpret_cast<const float4*>(p_a + mrow * p_lda + k_begin + kc[j]);
         }
+        // Every other kernel argument is pulled into SGPRs here, in one batch of scalar loads.  The argument block of a fresh
+        // dispatch is cold in the scalar cache and each miss is a round trip to memory (~0.5 us); left to itself the compiler
+        // loads a field where it is first used, behind a branch on an earlier field, which chained five to six such round
+        // trips through the kernel (measured with tools/stamps_skinny.py: 2.3 us before the first weight load was issued).
+        asm volatile("" ::"s"(a.A), "s"(a.amap.ld), "s"(a.W), "s"(a.ldw), "s"(a.Wt), "s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R),
+                     "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
+        asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.pgate), "s"(fu.ldpg), "s"(fu.x_out), "s"(fu.ln),
+                     "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out));
         float4 lw[(PRO & PRO_AFFINE) ? NJ : 1], lb[(PRO & PRO_AFFINE) ? NJ : 1], lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
         auto load_params = [&]() {
             if constexpr ((PRO & PRO_AFFINE) != 0) {
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
         };
         if constexpr ((PRO & PRO_PARTIAL) != 0) {   // x += sum_z partial[z] + bias; the partials are added in a fixed order
             // the linear's output is summed first, then added to x, like the reference's y = W x + b; x += y
-            const float* pp = fu.partial + mrow * a.K;
+            const float* pp = fu.partial + mrow * p_k;
             float4 ps[NJ];
 #pragma unroll
             for (int j = 0; j < NJ; j++) ps[j] = *reinterpret_cast<const float4*>(pp + kc[j]);
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
             if (fu.x_out && blockIdx.x == 0 && m_ok) {
 #pragma unroll
                 for (int j = 0; j < NJ; j++)
-                    if (kok[j]) *reinterpret_cast<float4*>(fu.x_out + (int64_t)m * a.K + (lane + 64 * j) * 4) = xr[j];
+                    if (kok[j]) *reinterpret_cast<float4*>(fu.x_out + (int64_t)m * p_k + (lane + 64 * j) * 4) = xr[j];
             }
         } else {
             load_params();
@@ -213,7 +217,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < NJ; j++) s += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
-            const float mean = wave_sum_dpp(s) / (float)a.K;
+            const float mean = wave_sum_dpp(s) / (float)p_k;
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
                     v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
                 }
             }
-            const float inv_std = 1.0f / sqrtf(wave_sum_dpp(v) / (float)a.K + fu.eps);
+            const float inv_std = 1.0f / sqrtf(wave_sum_dpp(v) / (float)p_k + fu.eps);
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 float4 o;
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
                 }
                 if (!kok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
                 xr[j] = o;
-                if (fu.y_out && blockIdx.x == 0 && m_ok && kok[j]) *reinterpret_cast<float4*>(fu.y_out + (int64_t)m * a.K + (lane + 64 * j) * 4) = o;
+                if (fu.y_out && blockIdx.x == 0 && m_ok && kok[j]) *reinterpret_cast<float4*>(fu.y_out + (int64_t)m * p_k + (lane + 64 * j) * 4) = o;
             }
         }
         SK_STAMP(2);
@@ -306,14 +310,14 @@ __global__ __launch_bounds__(1024) void k_skinny(GemmArgs a, SkinnyFuse fu, int 
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             int m = m0 + q * 4 + reg;
-            if (m < a.M) partial[((int64_t)z * a.M + m) * a.N + n] = acc[reg];
+            if (m < p_m) partial[((int64_t)z * p_m + m) * p_n + n] = acc[reg];
         }
         return;
     }
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         int m = m0 + q * 4 + reg;
-        if (m >= a.M) continue;
+        if (m >= p_m) continue;
         float v = acc[reg] + e_bias;
         int64_t co = (int64_t)m * a.cmap.ld + n;
         switch (a.epi) {
@@ -350,8 +354,8 @@ unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_sta
 
 template <bool WBF16, int PRO, int NJ>
 static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
-    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ>), grid, dim3(1024), 0, stream, a, fu, splitk, partial, g_skinny_stamps);
-    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ>), grid, dim3(1024), 0, stream, a, fu, splitk, partial, nullptr);
+    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, g_skinny_stamps);
+    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
 }
 
 template <bool WBF16, int PRO>
