@@ -31,6 +31,12 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
     char* kbase = (char*)a.k + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * (KVBF16 ? 2 : 4);
     char* vbase = (char*)a.v + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * (KVBF16 ? 2 : 4);
     float* outp = a.out + (int64_t)seg * a.out_ld + h * 64;
+    // shared prefix (speed only: the rows are also in the cache): identical for every utterance of a voice, so the batch
+    // reads one L2-resident copy instead of B private ones from HBM
+    const int pre = a.pre_len ? a.pre_len[seg] : 0;
+    const int64_t pre_off = ((int64_t)a.layer * a.heads + h) * pre * 64 * (KVBF16 ? 2 : 4);
+    const char* pk = pre ? (const char*)a.pre_k[seg] + pre_off : kbase;
+    const char* pv = pre ? (const char*)a.pre_v[seg] + pre_off : vbase;
     if (!live) {   // uniform per block
         if (tid < 64) outp[tid] = 0.0f;
         return;
@@ -63,8 +69,8 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
     for (int i = 0; i < ATT_NI; i++) {
         const int jj = (i * 4 + wave) * KPI + kq;
         if (jj < nk) {
-            kr[i] = *reinterpret_cast<const uint4*>(kbase + ((int64_t)jj * 64 + sub * DPL) * (KVBF16 ? 2 : 4));
-            vr[i] = *reinterpret_cast<const uint4*>(vbase + ((int64_t)jj * 64 + sub * DPL) * (KVBF16 ? 2 : 4));
+            kr[i] = *reinterpret_cast<const uint4*>((jj < pre ? pk : kbase) + ((int64_t)jj * 64 + sub * DPL) * (KVBF16 ? 2 : 4));
+            vr[i] = *reinterpret_cast<const uint4*>((jj < pre ? pv : vbase) + ((int64_t)jj * 64 + sub * DPL) * (KVBF16 ? 2 : 4));
         } else {
             kr[i] = make_uint4(0, 0, 0, 0);
             vr[i] = make_uint4(0, 0, 0, 0);

@@ -133,6 +133,9 @@ struct AttnArgs {
     int fused_step = 0; const float* qkv = nullptr; int64_t qkv_ld = 0; int d_model = 0;
     const float* cos_t = nullptr; const float* sin_t = nullptr; int64_t cap = 0;
     const int32_t* active = nullptr;    // per segment; inactive rows write zeros and append nothing
+    // fused step only: keys j < pre_len[seg] are read from a shared prefix (a device voice, [layer][head][pre_len][hd] in the
+    // cache dtype) instead of the segment's own cache rows
+    const void* const* pre_k = nullptr; const void* const* pre_v = nullptr; const int32_t* pre_len = nullptr; int layer = 0;
 };
 void launch_attention(const AttnArgs& a, hipStream_t stream);   // picks k_attn_step for the fused AR step when the cache fits one burst
 bool attn_step_supported(const AttnArgs& a);

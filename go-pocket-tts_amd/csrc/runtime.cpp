@@ -156,6 +156,8 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     b->st.frames_after_eos = s + 7 * B; b->st.broke = s + 8 * B; b->st.n_active = s + 9 * B;
     b->st.eos_threshold = b->state_f32.as<float>();
     b->kv_len_host.assign(B, 0);
+    b->pre_k.ensure((size_t)B * sizeof(void*)); b->pre_v.ensure((size_t)B * sizeof(void*)); b->pre_len.ensure((size_t)B * sizeof(int32_t));
+    b->pre_k_host.assign(B, nullptr); b->pre_v_host.assign(B, nullptr); b->pre_len_host.assign(B, 0);
     const size_t f = sizeof(float);
     const int NA = d.ada_all.out;
     b->in_raw.ensure(B * d.ldim * f); b->in32.ensure(B * d.ldim * f);
@@ -188,6 +190,8 @@ void batch_reset(Batch& b) {
     std::vector<float> thr((size_t)B, INFINITY);
     h2d(b.st.eos_threshold, thr.data(), thr.size() * sizeof(float), s);
     std::fill(b.kv_len_host.begin(), b.kv_len_host.end(), 0);
+    std::fill(b.pre_len_host.begin(), b.pre_len_host.end(), 0);
+    launch_fill_i32(b.pre_len.as<int32_t>(), 0, B, s);
     b.has_noise = false;
 }
 
@@ -232,8 +236,14 @@ void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slo
     for (int l = 0; l < d.n_layers; l++)
         launch_voice_apply((const char*)v.k.p + lb * l, (const char*)v.v.p + lb * l, v.offset, d.heads, d.hd, ds.as<int32_t>(), (int)slots.size(),
                            b.kc(l), b.vc(l), (int)b.kv_elem(), b.cap, m.stream);
-    for (int32_t sl : slots) b.kv_len_host[sl] = v.offset;
+    for (int32_t sl : slots) {
+        b.kv_len_host[sl] = v.offset;
+        b.pre_k_host[sl] = v.k.p; b.pre_v_host[sl] = v.v.p; b.pre_len_host[sl] = v.offset;
+    }
     h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)b.B * sizeof(int32_t), m.stream);
+    h2d(b.pre_k.p, b.pre_k_host.data(), (size_t)b.B * sizeof(void*), m.stream);
+    h2d(b.pre_v.p, b.pre_v_host.data(), (size_t)b.B * sizeof(void*), m.stream);
+    h2d(b.pre_len.p, b.pre_len_host.data(), (size_t)b.B * sizeof(int32_t), m.stream);
 }
 
 void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64_t* steps, const int64_t* offsets) {
@@ -251,6 +261,8 @@ void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64
     }
     b.kv_len_host[slot] = (int32_t)offsets[0];
     h2d(b.st.kv_len + slot, &b.kv_len_host[slot], sizeof(int32_t), m.stream);
+    b.pre_len_host[slot] = 0;
+    h2d(b.pre_len.as<int32_t>() + slot, &b.pre_len_host[slot], sizeof(int32_t), m.stream);
 }
 
 // FlowLM.PromptText -> flowTransformer.prefill (flow_lm.go:155-187, flow_transformer.go:749-771), all slots at once,
@@ -438,6 +450,7 @@ void step_core(Batch& b, int lsd) {
         a.rows = B; a.heads = d.heads; a.max_keys = b.cap;
         a.fused_step = 1; a.qkv = qkv; a.qkv_ld = 3 * D; a.d_model = D;
         a.cos_t = m.at<float>(d.rope_cos); a.sin_t = m.at<float>(d.rope_sin); a.cap = b.cap;
+        a.pre_k = b.pre_k.as<const void*>(); a.pre_v = b.pre_v.as<const void*>(); a.pre_len = b.pre_len.as<int32_t>(); a.layer = l;
         launch_attention(a, s);
         {
             GemmArgs go = mk(m, attn, flat(D), L.out_proj, x, flat(D), B);

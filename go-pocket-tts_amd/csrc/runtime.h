@@ -77,6 +77,11 @@ struct Batch {
     DevBuf state_f32;
     StepState st{};
     std::vector<int32_t> kv_len_host;
+    // shared voice prefix: slots that took their first keys from a device-resident voice read them from the voice's own copy
+    // in the AR step (one copy for the whole batch stays in L2) instead of from their private cache rows
+    DevBuf pre_k, pre_v, pre_len;          // [B] device pointers to layer 0 of the voice's K / V, [B] prefix length (0: none)
+    std::vector<const void*> pre_k_host, pre_v_host;
+    std::vector<int32_t> pre_len_host;
     // step workspace
     DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step, partial, x2;
     DevBuf latents;          // [B][max_steps][ldim]
