@@ -148,6 +148,9 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     size_t kvbytes = (size_t)d.n_layers * B * d.heads * cap * d.hd * b->kv_elem();
     b->kcache.ensure(kvbytes);
     b->vcache.ensure(kvbytes);
+    // the step attention re-reads a valid row for key slots past the end (zero weight): every row must hold finite data
+    PTTS_HIP(hipMemsetAsync(b->kcache.p, 0, kvbytes, m.stream));
+    PTTS_HIP(hipMemsetAsync(b->vcache.p, 0, kvbytes, m.stream));
     b->state_i32.ensure((9 * B + 1) * sizeof(int32_t));
     b->state_f32.ensure(B * sizeof(float));
     int32_t* s = b->state_i32.as<int32_t>();
