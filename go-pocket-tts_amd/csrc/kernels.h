@@ -42,6 +42,7 @@ struct GemmArgs {
     const float* scale = nullptr;    // [N]
     const float* gate = nullptr; int64_t ldg = 0;
     float alpha = 1.0f;
+    float* tail = nullptr;           // k_skinny only: the LAST column goes, as acc + bias without the epilogue, to tail[m] instead of C
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
 };
@@ -191,9 +192,15 @@ struct StepState {
     int32_t* n_active;      // [1]
     int32_t* broke;         // [B] 1 when the loop left through the countdown `break` (no StepCallback for that step)
 };
-// prepares the step input: in32[b] = step==0 ? bos : latents[b][step-1] with NaN -> bos
+// prepares the step input: in32[b] = step==0 ? bos : latents[b][step-1] with NaN -> bos, x0[b] = noise of the step (or 0);
+// with `lin` also x = input_linear(in32) and fx = input_proj(x0) (the two ldim-wide linears of the step, exact f32)
+struct StepOpenLinears {
+    const void* w_in = nullptr; const float* b_in = nullptr; int d_in = 0; float* x = nullptr;     // [d_in][ldim] row-major
+    const void* w_pj = nullptr; const float* b_pj = nullptr; int d_pj = 0; float* fx = nullptr;    // [d_pj][ldim]
+    int w_bf16 = 0;
+};
 void launch_step_begin(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
-                       int ldim, int b, float* in32, float* x0, hipStream_t stream);
+                       int ldim, int b, float* in32, float* x0, const StepOpenLinears* lin, hipStream_t stream);
 // stores the decoded frame, applies EOS logic, advances kv_len/step
 void launch_step_finish(const StepState& s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,
                         int64_t lat_stride, hipStream_t stream);

@@ -620,22 +620,61 @@ void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipSt
 // ------------------------------------------------------------------------------------------------
 // AR-step bookkeeping: the per-utterance loop state of runtime_native_safetensors.go:150-201 on device
 // ------------------------------------------------------------------------------------------------
-// One launch opens the step: the model input of every utterance (previous latent, or the BOS marker replaced by bos_emb:
-// newBOSSequenceTensor :246-253 + replaceNaNWithVector) and the starting point of the flow (this step's noise or zeros).
-__global__ void k_step_begin(StepState s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
-                             int ldim, int b, float* in32, float* x0) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= b * ldim) return;
-    int bi = i / ldim, e = i % ldim;
-    int st = s.step[bi];
-    float v = st == 0 ? NAN : latents[(int64_t)bi * lat_stride + (int64_t)(st - 1) * ldim + e];
-    in32[i] = isnan(v) ? bos[e] : v;
-    x0[i] = noise ? noise[(int64_t)bi * noise_stride + (int64_t)st * ldim + e] : 0.0f;
+// One launch opens the step.  Per utterance: the model input (previous latent, or the BOS marker replaced by bos_emb:
+// newBOSSequenceTensor :246-253 + replaceNaNWithVector) and the starting point of the flow (this step's noise or zeros);
+// then, when the two 32-wide linears are handed in, what they feed: x = input_linear(input) (flow_lm.go:254) and
+// fx = input_proj(start) (flow_net.go:327) -- 32 multiply-adds per output in exact f32, not worth a launch each.
+template <bool WBF16>
+__global__ __launch_bounds__(256) void k_step_begin(StepState s, const float* latents, int64_t lat_stride, const float* bos, const float* noise,
+                                                    int64_t noise_stride, int ldim, float* in32, float* x0, const void* w_in, const float* b_in, int d_in,
+                                                    float* x, const void* w_pj, const float* b_pj, int d_pj, float* fx) {
+    __shared__ float vin[64], vst[64];
+    const int bi = blockIdx.y, tid = threadIdx.x;
+    if (tid < ldim) {
+        const int st = s.step[bi];
+        const float v = st == 0 ? NAN : latents[(int64_t)bi * lat_stride + (int64_t)(st - 1) * ldim + tid];
+        const float vi = isnan(v) ? bos[tid] : v;
+        const float vs = (noise && st < s.max_steps[bi]) ? noise[(int64_t)bi * noise_stride + (int64_t)st * ldim + tid] : 0.0f;   // a finished utterance has no row `st`
+        vin[tid] = vi;
+        vst[tid] = vs;
+        if (blockIdx.x == 0) { in32[bi * ldim + tid] = vi; x0[bi * ldim + tid] = vs; }
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 256 + tid;
+    if (!w_in || n >= d_in + d_pj) return;
+    const bool first = n < d_in;
+    const int row = first ? n : n - d_in;
+    const float* vec = first ? vin : vst;
+    const char* wrow = (const char*)(first ? w_in : w_pj) + (int64_t)row * ldim * (WBF16 ? 2 : 4);
+    const float* bias = first ? b_in : b_pj;
+    float acc = 0.0f;
+    for (int k = 0; k < ldim; k += 4) {   // ldim % 4 == 0 (host)
+        float w0, w1, w2, w3;
+        if (WBF16) {
+            const uint2 u = *reinterpret_cast<const uint2*>(wrow + k * 2);
+            w0 = __uint_as_float(u.x << 16); w1 = __uint_as_float(u.x & 0xffff0000u); w2 = __uint_as_float(u.y << 16); w3 = __uint_as_float(u.y & 0xffff0000u);
+        } else {
+            const float4 u = *reinterpret_cast<const float4*>(wrow + k * 4);
+            w0 = u.x; w1 = u.y; w2 = u.z; w3 = u.w;
+        }
+        acc = fmaf(w0, vec[k], acc); acc = fmaf(w1, vec[k + 1], acc); acc = fmaf(w2, vec[k + 2], acc); acc = fmaf(w3, vec[k + 3], acc);
+    }
+    acc += bias ? bias[row] : 0.0f;
+    if (first) x[(int64_t)bi * d_in + row] = acc;
+    else fx[(int64_t)bi * d_pj + row] = acc;
 }
 void launch_step_begin(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
-                       int ldim, int b, float* in32, float* x0, hipStream_t stream) {
-    hipLaunchKernelGGL(k_step_begin, dim3((b * ldim + 255) / 256), dim3(256), 0, stream, s, latents, lat_stride, bos, noise, noise_stride, ldim, b,
-                       in32, x0);
+                       int ldim, int b, float* in32, float* x0, const StepOpenLinears* lin, hipStream_t stream) {
+    const int cols = lin ? lin->d_in + lin->d_pj : 0;
+    dim3 grid(lin ? (cols + 255) / 256 : 1, b);
+    const void* w_in = lin ? lin->w_in : nullptr;
+    if (lin && lin->w_bf16)
+        hipLaunchKernelGGL(k_step_begin<true>, grid, dim3(256), 0, stream, s, latents, lat_stride, bos, noise, noise_stride, ldim, in32, x0, w_in,
+                           lin->b_in, lin->d_in, lin->x, lin->w_pj, lin->b_pj, lin->d_pj, lin->fx);
+    else
+        hipLaunchKernelGGL(k_step_begin<false>, grid, dim3(256), 0, stream, s, latents, lat_stride, bos, noise, noise_stride, ldim, in32, x0, w_in,
+                           lin ? lin->b_in : nullptr, lin ? lin->d_in : 0, lin ? lin->x : nullptr, lin ? lin->w_pj : nullptr,
+                           lin ? lin->b_pj : nullptr, lin ? lin->d_pj : 0, lin ? lin->fx : nullptr);
 }
 
 __global__ void k_step_finish(StepState s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,

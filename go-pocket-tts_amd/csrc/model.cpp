@@ -256,6 +256,20 @@ struct Walker {
             te.alpha = add_f32((size_t)f.at(p + ".mlp.3.alpha").count(), [&](float* dst) { f.decode_f32(p + ".mlp.3.alpha", dst); });
         }
         d.cond_embed = step_linear(fn + "cond_embed", true);
+        if (d.out_eos.in == d.cond_embed.in && d.out_eos.out == 1) {   // [cond_embed ; out_eos]: N = flow_dim + 1
+            const std::string n1 = fn + "cond_embed", n2 = fl + "out_eos";
+            const size_t c1 = (size_t)d.cond_embed.out * d.cond_embed.in, c2 = (size_t)d.out_eos.in;
+            d.cond_eos.out = d.cond_embed.out + 1;
+            d.cond_eos.in = d.cond_embed.in;
+            d.cond_eos.bf16 = d.cond_embed.bf16;
+            d.cond_eos.w = d.cond_embed.w;   // row-major copy of the first N-1 rows only: the stacked operand exists in tiled form alone
+            add_tiled(d.cond_eos, [&](float* dst) { f.decode_f32(n1 + ".weight", dst); f.decode_f32(n2 + ".weight", dst + c1); (void)c2; });
+            d.cond_eos.b = add_f32((size_t)d.cond_eos.out, [&](float* dst) {
+                std::fill(dst, dst + d.cond_eos.out, 0.0f);
+                if (has(n1 + ".bias")) f.decode_f32(n1 + ".bias", dst);
+                if (has(n2 + ".bias")) f.decode_f32(n2 + ".bias", dst + d.cond_embed.out);
+            });
+        }
         d.input_proj = step_linear(fn + "input_proj", true);
         d.flow_dim = d.input_proj.out;
         d.flow_depth = 0;

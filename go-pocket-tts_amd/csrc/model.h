@@ -38,6 +38,7 @@ struct Desc {
     int flow_dim = 0, flow_depth = 0, nfreq = 0;
     struct TE { size_t freqs = NONE, alpha = NONE; Lin l1, l2; } te[2];
     Lin cond_embed, input_proj, ada_all, final_linear;
+    Lin cond_eos;   // cond_embed with out_eos stacked as its last row: both read the out_norm rows, one launch (runtime.cpp step_core)
     struct RB { Norm ln; Lin mlp0, mlp2; } rb[MAX_LAYERS];
     // mimi (mimi.go:16-34,528-544)
     int mimi_dim = 0, mimi_heads = 8, mimi_hd = 0, mimi_layers = 0, mimi_ffn = 0, mimi_ctx = 250;

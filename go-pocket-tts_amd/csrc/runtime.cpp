@@ -422,7 +422,24 @@ static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const
 // -> [LN2 + linear1 + GELU] -> [linear2, split over K]; the split-K sum and its residual add ride in the next
 // layer's first launch.  The residual stream ping-pongs between two buffers so that no launch reads rows another
 // block of the same launch rewrites.
-void step_core(Batch& b, int lsd) {
+void step_open(Batch& b) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    const int ld = d.ldim;
+    const int64_t ls = (int64_t)b.max_steps * ld;
+    StepOpenLinears lin;
+    const bool ok = ld <= 64 && ld % 4 == 0 && d.input_linear.in == ld && d.input_proj.in == ld && d.input_linear.bf16 == d.input_proj.bf16;
+    if (ok) {
+        lin.w_in = m.arena + d.input_linear.w; lin.b_in = m.at<float>(d.input_linear.b); lin.d_in = d.input_linear.out; lin.x = b.x.as<float>();
+        lin.w_pj = m.arena + d.input_proj.w; lin.b_pj = m.at<float>(d.input_proj.b); lin.d_pj = d.input_proj.out; lin.fx = b.fx.as<float>();
+        lin.w_bf16 = d.input_linear.bf16;
+    }
+    b.opened = ok;
+    launch_step_begin(b.st, b.latents.as<float>(), ls, m.at<float>(d.bos), b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B,
+                      b.in32.as<float>(), b.cur.as<float>(), ok ? &lin : nullptr, m.stream);
+}
+
+void step_core(Batch& b, int lsd, bool opened) {
     Model& m = *b.m;
     const Desc& d = m.d;
     hipStream_t s = m.stream;
@@ -433,7 +450,7 @@ void step_core(Batch& b, int lsd) {
     float* qkv = b.qkv.as<float>();
     float* attn = b.attn.as<float>();
     float* ff = b.ff.as<float>();
-    step_gemm(m, mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B));
+    if (!opened) step_gemm(m, mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B));
     Pending pend;
     for (int l = 0; l < d.n_layers; l++) {
         const auto& L = d.layers[l];
@@ -496,9 +513,19 @@ void step_core(Batch& b, int lsd) {
         fu.ln = 1; fu.eps = in.eps; fu.ln_w = m.at<float>(d.out_norm.w); fu.ln_b = m.at<float>(d.out_norm.b);
         tail_fused = skinny_fuse_supported(g1, fu) && skinny_fuse_supported(g2, fu);
         if (tail_fused) {
-            step_fused_linear(b, x, in, d.out_eos, b.eos.as<float>(), 1, B, EPI_NONE, nullptr, nullptr, 1.0f);
             in.y_out = last;
-            step_fused_linear(b, x, in, d.cond_embed, sy, C, B, EPI_SILU, tc, nullptr, 1.0f);
+            if (d.cond_eos.wt != NONE) {   // one launch: columns 0..C-1 = cond_embed (SiLU epilogue), column C = out_eos (raw)
+                GemmArgs g = mk(m, x, flat(D), d.cond_eos, sy, flat(C), B);
+                g.epi = EPI_SILU; g.addvec = tc; g.tail = b.eos.as<float>();
+                SkinnyFuse f2 = fu;
+                f2.y_out = last;
+                step_gemm(m, g, f2);
+            } else {
+                in.y_out = nullptr;
+                step_fused_linear(b, x, in, d.out_eos, b.eos.as<float>(), 1, B, EPI_NONE, nullptr, nullptr, 1.0f);
+                in.y_out = last;
+                step_fused_linear(b, x, in, d.cond_embed, sy, C, B, EPI_SILU, tc, nullptr, 1.0f);
+            }
         } else {
             LnArgs ln = mkln(m, x, flat(D), d.out_norm, last, D, B);
             ln.partial = pend.partial; ln.splitk = pend.splitk; ln.pstride = pend.pstride; ln.pbias = pend.bias;
@@ -518,7 +545,7 @@ void step_core(Batch& b, int lsd) {
             step_gemm(m, gc);
         }
         step_gemm(m, mk(m, sy, flat(C), d.ada_all, ada, flat(NA), B));
-        step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
+        if (i > 0 || !opened) step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
         for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
             const auto& rb = d.rb[r];
             FusedIn in;
@@ -732,9 +759,8 @@ static void capture_step_graph(Batch& b, int lsd) {
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    launch_step_begin(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B,
-                      b.in32.as<float>(), b.cur.as<float>(), m.stream);
-    step_core(b, lsd);
+    step_open(b);
+    step_core(b, lsd, b.opened);
     launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
     PTTS_HIP(hipStreamEndCapture(m.stream, &g));
     hipError_t e = hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0);
@@ -752,9 +778,8 @@ static void enqueue_step(Batch& b, int lsd, bool use_graph) {
     }
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    launch_step_begin(b.st, b.latents.as<float>(), ls, m.at<float>(m.d.bos), b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B,
-                      b.in32.as<float>(), b.cur.as<float>(), m.stream);
-    step_core(b, lsd);
+    step_open(b);
+    step_core(b, lsd, b.opened);
     launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
 }
 

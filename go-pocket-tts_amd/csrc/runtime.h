@@ -87,6 +87,7 @@ struct Batch {
     DevBuf latents;          // [B][max_steps][ldim]
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;
+    bool opened = false;     // the last step_open also produced x and fx
     hipGraphExec_t graph = nullptr;
     int graph_lsd = 0;
     bool graph_noise = false;
@@ -126,7 +127,8 @@ void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64
 // rows: device [R, d_model]; row_offsets host [B+1]
 void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 // core of one AR step on device state: in32 [B, ldim], cur [B, ldim] (= x0) -> cur (= frame), eos, last; appends KV at kv_len
-void step_core(Batch& b, int lsd_steps);
+void step_core(Batch& b, int lsd_steps, bool opened = false);   // opened: x and fx were produced by step_open
+void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev);
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
 

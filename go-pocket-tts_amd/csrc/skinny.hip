@@ -109,7 +109,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     if (kq4 == 0 && splitk <= 1) {
         const int nc = n_ok ? n : 0;
         if (a.bias) e_bias = a.bias[nc];
-        if (a.addvec) e_addv = a.addvec[nc];
+        if (a.addvec) e_addv = a.addvec[(a.tail && nc == p_n - 1) ? 0 : nc];
         if (a.scale) e_scl = a.scale[nc];
         if (a.epi >= EPI_RESADD) {
 #pragma unroll
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         // loads a field where it is first used, behind a branch on an earlier field, which chained five to six such round
         // trips through the kernel (measured with tools/stamps_skinny.py: 2.3 us before the first weight load was issued).
         asm volatile("" ::"s"(a.A), "s"(a.amap.ld), "s"(a.W), "s"(a.ldw), "s"(a.Wt), "s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R),
-                     "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
+                     "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.tail), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
         asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.pgate), "s"(fu.ldpg), "s"(fu.x_out), "s"(fu.ln),
                      "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out));
         float4 lw[(PRO & PRO_AFFINE) ? NJ : 1], lb[(PRO & PRO_AFFINE) ? NJ : 1], lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
@@ -320,6 +320,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         if (m >= p_m) continue;
         float v = acc[reg] + e_bias;
         int64_t co = (int64_t)m * a.cmap.ld + n;
+        if (a.tail && n == p_n - 1) { a.tail[m] = v; continue; }
         switch (a.epi) {
             case EPI_NONE: break;
             case EPI_GELU: v = gelu1(v); break;
