@@ -175,7 +175,7 @@ int ptts_generate(ptts_model* h, const ptts_request* reqs, int32_t n, ptts_resul
 
 void ptts_free_result(ptts_result* r) {
     if (!r) return;
-    free(r->pcm);
+    result_free(r->pcm);
     free(r->latents);
     r->pcm = nullptr;
     r->latents = nullptr;

@@ -3,6 +3,8 @@
 // internal/native/{model,flow_lm,flow_transformer,flow_net,mimi}.go.
 #include "runtime.h"
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 
@@ -741,6 +743,63 @@ void mimi_decode(Model& m, const float* lat, int64_t lat_bstride, int B, int T, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// pinned result pool
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::map<void*, size_t> owned;                    // every live pinned block -> its (rounded) size
+    std::multimap<size_t, void*> free_blocks;         // size -> block
+    size_t free_bytes = 0;
+    static constexpr size_t kKeep = (size_t)1 << 30;  // keep at most 1 GiB of idle pinned memory
+};
+PinnedPool& pool() { static PinnedPool* p = new PinnedPool(); return *p; }   // leaked on purpose: results may outlive static destructors
+}  // namespace
+
+void* result_alloc(size_t bytes) {
+    const size_t sz = (std::max<size_t>(bytes, 1) + 65535) & ~(size_t)65535;
+    PinnedPool& pp = pool();
+    {
+        std::lock_guard<std::mutex> lock(pp.mu);
+        auto it = pp.free_blocks.lower_bound(sz);
+        if (it != pp.free_blocks.end() && it->first <= sz * 2) {
+            void* p = it->second;
+            pp.free_bytes -= it->first;
+            pp.free_blocks.erase(it);
+            return p;
+        }
+    }
+    void* p = nullptr;
+    if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return malloc(sz);   // still a valid result buffer, just a slower copy
+    }
+    std::lock_guard<std::mutex> lock(pp.mu);
+    pp.owned[p] = sz;
+    return p;
+}
+
+void result_free(void* p) {
+    if (!p) return;
+    PinnedPool& pp = pool();
+    size_t sz = 0;
+    {
+        std::lock_guard<std::mutex> lock(pp.mu);
+        auto it = pp.owned.find(p);
+        if (it == pp.owned.end()) { free(p); return; }
+        sz = it->second;
+        if (pp.free_bytes + sz <= PinnedPool::kKeep) {
+            pp.free_blocks.emplace(sz, p);
+            pp.free_bytes += sz;
+            return;
+        }
+        pp.owned.erase(it);
+    }
+    (void)hipHostFree(p);
+}
+
 // ------------------------------------------------------------------------------------------------
 // GenerateAudio for a batch of independent utterance chunks
 // ------------------------------------------------------------------------------------------------
@@ -790,6 +849,17 @@ static void fail_req(ptts_result& r, int code) {
 static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector<int>& idx, ptts_result* res, int lsd) {
     const Desc& d = m.d;
     hipStream_t s = m.stream;
+    // PTTS_TRACE=1: host wall time of the phases of one call (stderr); each mark drains the stream first
+    static const bool trace = getenv("PTTS_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(m.stream2);
+        auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ptts] %-12s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
     const int B = (int)idx.size(), D = d.d_model, ld = d.ldim;
     std::vector<int> ms((size_t)B), tp((size_t)B), off((size_t)B);
     int cap_need = 0, ms_max = 0;
@@ -846,7 +916,9 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             id0 += r.n_tokens;
         }
     }
+    mark("setup");
     batch_prompt(b, rows.as<float>(), row_off.data());
+    mark("prefill");
     // injected sampling noise (flow_lm.go:283-288)
     bool any_noise = false;
     for (int i = 0; i < B; i++) any_noise |= reqs[idx[i]].noise != nullptr;
@@ -919,6 +991,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             if (*b.n_active_pinned <= 0) break;
         }
     }
+    mark("ar loop");
     std::vector<int32_t> nf((size_t)B), es((size_t)B);
     d2h(nf.data(), b.st.n_frames, (size_t)B * 4, s);
     d2h(es.data(), b.st.eos_step, (size_t)B * 4, s);
@@ -927,15 +1000,17 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     if (Tmax > 0) {
         decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
         PTTS_HIP(hipStreamSynchronize(m.stream2));
+        mark("mimi");
         for (int i = 0; i < B; i++) {
             ptts_result& r = res[idx[i]];
             if (cancelled[i]) { fail_req(r, PTTS_ECANCELLED); continue; }
             r.n_frames = nf[i];
             r.eos_step = es[i];
             r.n_samples = (int64_t)nf[i] * spf;
-            r.pcm = (float*)malloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
+            r.pcm = (float*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
             if (!r.pcm) { fail_req(r, PTTS_ENOMEM); continue; }
-            d2h(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), s);
+            if (r.n_samples > 0)   // all copies are queued back to back; one wait below
+                PTTS_HIP(hipMemcpyAsync(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), hipMemcpyDeviceToHost, s));
             if (reqs[idx[i]].want_latents) {
                 r.latents = (float*)malloc((size_t)std::max(1, nf[i]) * ld * sizeof(float));
                 if (!r.latents) { fail_req(r, PTTS_ENOMEM); continue; }
@@ -943,6 +1018,8 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             }
             r.status = PTTS_OK;
         }
+        PTTS_HIP(hipStreamSynchronize(s));
+        mark("results d2h");
     } else {
         PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int i = 0; i < B; i++) fail_req(res[idx[i]], PTTS_ECANCELLED);
