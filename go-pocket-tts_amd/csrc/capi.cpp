@@ -176,11 +176,19 @@ int ptts_generate(ptts_model* h, const ptts_request* reqs, int32_t n, ptts_resul
 void ptts_free_result(ptts_result* r) {
     if (!r) return;
     result_free(r->pcm);
+    result_free(r->pcm16);
     free(r->latents);
     r->pcm = nullptr;
+    r->pcm16 = nullptr;
     r->latents = nullptr;
     r->n_samples = 0;
     r->n_frames = 0;
+}
+
+void ptts_wav_header_streaming(uint8_t out[44]) {   // internal/audio/wav_stream.go:15-41
+    static const uint8_t hdr[44] = {'R', 'I', 'F', 'F', 0xFF, 0xFF, 0xFF, 0xFF, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 1, 0,
+                                    0xC0, 0x5D, 0, 0 /* 24000 */, 0x80, 0xBB, 0, 0 /* 48000 B/s */, 2, 0, 16, 0, 'd', 'a', 't', 'a', 0xFF, 0xFF, 0xFF, 0xFF};
+    memcpy(out, hdr, 44);
 }
 
 int ptts_voice_create(ptts_model* h, const float* const* caches, const int64_t* steps, const int64_t* offsets, ptts_voice** out) {
@@ -594,6 +602,19 @@ int ptts_op_linear(const float* x, const float* w, const float* bias, int64_t ro
         launch_gemm(g, nullptr);
         PTTS_HIP(hipDeviceSynchronize());
         down(y, dy.p, (size_t)rows * out * 4);
+    });
+}
+
+int ptts_op_pcm16(const float* samples, int64_t n, int16_t* out) {
+    return guard([&] {
+        require_device();
+        if (n < 0 || (n > 0 && (!samples || !out))) throw Error(PTTS_EINVAL, "audio: pcm16 requires non-nil buffers");
+        if (n == 0) return;
+        Tmp dx((size_t)n * 4), dy((size_t)n * 2);
+        up(dx.p, samples, (size_t)n * 4);
+        launch_pcm16(dx.as<float>(), dy.as<int16_t>(), n, nullptr);
+        PTTS_HIP(hipDeviceSynchronize());
+        down(out, dy.p, (size_t)n * 2);
     });
 }
 

@@ -606,6 +606,36 @@ void launch_conv_final(const float* in, int in_pad_rows, const float* w, const f
     hipLaunchKernelGGL(k_conv_final, dim3((unsigned)(b * tiles)), dim3(256), lds, stream, in, in_pad_rows, w, bias, b, t, t0, t1, c, k, elu_in, out);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// PCM egress: audio.WritePCM16Samples on the device -- halves the bytes that cross PCIe
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int pcm16_one(float s) {
+    double c = (double)s;                       // the reference clamps and multiplies in float64: the product is exact
+    c = c > 1.0 ? 1.0 : c;
+    c = c < -1.0 ? -1.0 : c;
+    return s != s ? 0 : (int)(c * 32767.0);     // float -> int conversion truncates toward zero, like Go's int16(x)
+}
+__global__ void k_pcm16(const float* in, int16_t* out, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4 a = *reinterpret_cast<const float4*>(in + i), b = *reinterpret_cast<const float4*>(in + i + 4);
+        uint4 o;
+        o.x = (unsigned)(pcm16_one(a.x) & 0xffff) | ((unsigned)pcm16_one(a.y) << 16);
+        o.y = (unsigned)(pcm16_one(a.z) & 0xffff) | ((unsigned)pcm16_one(a.w) << 16);
+        o.z = (unsigned)(pcm16_one(b.x) & 0xffff) | ((unsigned)pcm16_one(b.y) << 16);
+        o.w = (unsigned)(pcm16_one(b.z) & 0xffff) | ((unsigned)pcm16_one(b.w) << 16);
+        *reinterpret_cast<uint4*>(out + i) = o;
+    } else {
+        for (int64_t j = i; j < n; j++) out[j] = (int16_t)pcm16_one(in[j]);
+    }
+}
+void launch_pcm16(const float* in, int16_t* out, int64_t n, hipStream_t stream) {
+    if (n <= 0) return;
+    const int64_t threads = (n + 7) / 8;
+    hipLaunchKernelGGL(k_pcm16, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, in, out, n);
+}
+
 __global__ void k_zero_rows(float* base, int64_t batch_stride, int b, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)b * n) return;

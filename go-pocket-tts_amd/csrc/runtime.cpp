@@ -1000,6 +1000,15 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     if (Tmax > 0) {
         decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
         PTTS_HIP(hipStreamSynchronize(m.stream2));
+        DevBuf* pcm_s16 = nullptr;   // PCM16 egress on the device (audio/wav_stream.go:43-54) for the requests that ask for it
+        {
+            bool any_s16 = false;
+            for (int i = 0; i < B; i++) any_s16 |= reqs[idx[i]].pcm_format == PTTS_PCM_S16 && !cancelled[i];
+            if (any_s16) {
+                pcm_s16 = &m.work(8, (size_t)B * T * spf * sizeof(int16_t));
+                launch_pcm16(pcm.as<float>(), pcm_s16->as<int16_t>(), (int64_t)B * T * spf, s);
+            }
+        }
         mark("mimi");
         for (int i = 0; i < B; i++) {
             ptts_result& r = res[idx[i]];
@@ -1007,10 +1016,17 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             r.n_frames = nf[i];
             r.eos_step = es[i];
             r.n_samples = (int64_t)nf[i] * spf;
-            r.pcm = (float*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
-            if (!r.pcm) { fail_req(r, PTTS_ENOMEM); continue; }
-            if (r.n_samples > 0)   // all copies are queued back to back; one wait below
-                PTTS_HIP(hipMemcpyAsync(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), hipMemcpyDeviceToHost, s));
+            if (reqs[idx[i]].pcm_format == PTTS_PCM_S16) {
+                r.pcm16 = (int16_t*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(int16_t));
+                if (!r.pcm16) { fail_req(r, PTTS_ENOMEM); continue; }
+                if (r.n_samples > 0)
+                    PTTS_HIP(hipMemcpyAsync(r.pcm16, pcm_s16->as<int16_t>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(int16_t), hipMemcpyDeviceToHost, s));
+            } else {
+                r.pcm = (float*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
+                if (!r.pcm) { fail_req(r, PTTS_ENOMEM); continue; }
+                if (r.n_samples > 0)   // all copies are queued back to back; one wait below
+                    PTTS_HIP(hipMemcpyAsync(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), hipMemcpyDeviceToHost, s));
+            }
             if (reqs[idx[i]].want_latents) {
                 r.latents = (float*)malloc((size_t)std::max(1, nf[i]) * ld * sizeof(float));
                 if (!r.latents) { fail_req(r, PTTS_ENOMEM); continue; }

@@ -59,7 +59,7 @@ class _Request(C.Structure):
                 ("frames_after_eos", C.c_int32), ("voice_embedding", _FP), ("voice_frames", C.c_int64),
                 ("voice_caches", C.POINTER(_FP)), ("voice_cache_steps", _IP), ("voice_offsets", _IP), ("noise", _FP),
                 ("step_callback", _STEP_CB), ("callback_user", C.c_void_p), ("cancel", C.POINTER(C.c_int32)),
-                ("want_latents", C.c_int32), ("reserved0", C.c_int32), ("voice", C.c_void_p), ("reserved", C.c_int32 * 4)]
+                ("want_latents", C.c_int32), ("pcm_format", C.c_int32), ("voice", C.c_void_p), ("reserved", C.c_int32 * 4)]
 
 
 class _Profile(C.Structure):
@@ -68,7 +68,7 @@ class _Profile(C.Structure):
 
 class _Result(C.Structure):
     _fields_ = [("pcm", _FP), ("n_samples", C.c_int64), ("latents", _FP), ("n_frames", C.c_int32), ("eos_step", C.c_int32),
-                ("status", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("status", C.c_int32), ("pcm16", C.POINTER(C.c_int16)), ("reserved", C.c_int32 * 2)]
 
 
 _lib = None
@@ -82,7 +82,7 @@ ABI_SYMBOLS = [
     "ptts_decode_latents", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
-    "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host",
+    "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
 ]
 
 
@@ -202,6 +202,7 @@ class RuntimeGenerateConfig:
     noise: Optional[np.ndarray] = None
     cancel: Optional[np.ndarray] = None  # int32[1]; nonzero = cancelled (the ctx of GenerateAudio)
     want_latents: bool = False
+    pcm16: bool = False   # PCM egress on the device: GenerateResult.pcm is int16 = audio.WritePCM16Samples (wav_stream.go:43-54)
 
 
 @dataclass
@@ -370,13 +371,17 @@ class Model:
             if cfg.cancel is not None:
                 r.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
             r.want_latents = 1 if cfg.want_latents else 0
+            r.pcm_format = 1 if getattr(cfg, "pcm16", False) else 0
         rc = lib().ptts_generate(self.h, reqs, n, ress)
         out = []
         try:
             _check(rc)
             for i in range(n):
                 rs = ress[i]
-                pcm = np.ctypeslib.as_array(rs.pcm, (rs.n_samples,)).copy() if rs.n_samples else np.zeros(0, np.float32)
+                if getattr(cfgs[i], "pcm16", False):   # PCM16 egress: int16 samples encoded on the device
+                    pcm = np.ctypeslib.as_array(rs.pcm16, (rs.n_samples,)).copy() if rs.n_samples else np.zeros(0, np.int16)
+                else:
+                    pcm = np.ctypeslib.as_array(rs.pcm, (rs.n_samples,)).copy() if rs.n_samples else np.zeros(0, np.float32)
                 lat = None
                 if cfgs[i].want_latents:
                     lat = np.ctypeslib.as_array(rs.latents, (rs.n_frames, self.info.ldim)).copy()
@@ -583,3 +588,20 @@ def op_convtr1d_righttrim(x, w, bias, stride: int, groups: int = 1) -> np.ndarra
     ba = _f32(bias) if bias is not None else None
     _check(lib().ptts_op_convtr1d_righttrim(_fp(x), _fp(w), _fp(ba), b, cin, ln, opg, k, stride, groups, _fp(y)))
     return y
+
+
+def wav_header_streaming() -> bytes:
+    """audio.WriteWAVHeaderStreaming (internal/audio/wav_stream.go:15-41): the 44 bytes in front of a PCM16 stream."""
+    buf = (C.c_uint8 * 44)()
+    lib().ptts_wav_header_streaming(buf)
+    return bytes(buf)
+
+
+def op_pcm16(samples) -> np.ndarray:
+    """audio.WritePCM16Samples on the device."""
+    x = np.ascontiguousarray(samples, np.float32).reshape(-1)
+    out = np.zeros(x.size, np.int16)
+    L = lib()
+    L.ptts_op_pcm16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    _check(L.ptts_op_pcm16(x.ctypes.data, x.size, out.ctypes.data))
+    return out

@@ -94,6 +94,9 @@ void   ptts_plan_free(ptts_plan* p);
 /* ---- the Runtime seam: tts.Runtime.GenerateAudio (runtime_native_safetensors.go:52-238) ---- */
 typedef void (*ptts_step_callback)(void* user, int32_t step, int32_t max_steps); /* RuntimeGenerateConfig.StepCallback */
 
+#define PTTS_PCM_F32 0
+#define PTTS_PCM_S16 1
+
 typedef struct ptts_request {
     const int64_t* tokens; int64_t n_tokens;          /* must be non-empty (:57-59) */
     float   temperature;                              /* only validates `noise`: <=0 means zero noise (flow_lm.go:395-404) */
@@ -113,7 +116,7 @@ typedef struct ptts_request {
     ptts_step_callback step_callback; void* callback_user;
     const volatile int32_t* cancel;                   /* polled between steps; nonzero -> PTTS_ECANCELLED */
     int32_t want_latents;                             /* 1: also return the latent frames */
-    int32_t reserved0;
+    int32_t pcm_format;                               /* PTTS_PCM_F32 (0): result.pcm; PTTS_PCM_S16 (1): result.pcm16, encoded on the device */
     /* a voice model state already resident in HBM (ptts_voice_create); exclusive with the two host forms above.
      * The reference loads the voice file once per Synthesize call and rebuilds the FlowLM state from it for
      * every chunk (service.go:127,216-246, flow_lm.go:134-145); the device copy is that cached voice. */
@@ -126,13 +129,19 @@ typedef struct ptts_result {
     float*  latents;   int32_t n_frames;              /* [n_frames, ldim] when want_latents */
     int32_t eos_step;                                 /* first step whose EOS logit crossed the threshold, -1 if none */
     int32_t status;                                   /* per-request PTTS_* code */
-    int32_t reserved[4];
+    int16_t* pcm16;                                   /* PTTS_PCM_S16: n_samples little-endian samples, v = int16(clamp(s, -1, 1) * 32767)
+                                                       * exactly as audio.WritePCM16Samples (internal/audio/wav_stream.go:43-54); pcm is NULL then */
+    int32_t reserved[2];
 } ptts_result;
 
 /* n_reqs == 1 reproduces GenerateAudio exactly.  n_reqs > 1 is this library's batching
  * extension: independent utterance chunks stepped together (per-row EOS countdown, ragged KV). */
 int  ptts_generate(ptts_model* m, const ptts_request* reqs, int32_t n_reqs, ptts_result* results);
 void ptts_free_result(ptts_result* r);
+
+/* The 44-byte header audio.WriteWAVHeaderStreaming emits in front of a PCM16 stream (internal/audio/wav_stream.go:15-41):
+ * 24 kHz, mono, 16 bit, RIFF and data sizes 0xFFFFFFFF. */
+void ptts_wav_header_streaming(uint8_t out[44]);
 
 /* Uploads a voice model state ([2,1,T,H,Dh] f32 per layer + offsets; safetensors.LoadVoiceModelState,
  * reader.go:127-140,273-308) once; requests then reference it by handle. */
@@ -197,6 +206,9 @@ int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, in
                              int32_t max_blocks, int32_t* n_blocks);
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
+
+/* audio.WritePCM16Samples on the device (internal/audio/wav_stream.go:43-54), without the byte packing */
+int ptts_op_pcm16(const float* samples, int64_t n, int16_t* out);
 
 const char* ptts_version(void);
 

@@ -646,3 +646,24 @@ class OracleState:
                 self.h = None
         except Exception:  # noqa: BLE001
             pass
+
+
+def pcm16(samples) -> np.ndarray:
+    """audio.WritePCM16Samples (wav_stream.go:43-54) without the byte packing: int16 per sample."""
+    x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+    out = np.zeros(x.size, dtype=np.int16)
+    L = lib()
+    L.po_pcm16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.po_pcm16.restype = None
+    L.po_pcm16(x.ctypes.data, x.size, out.ctypes.data)
+    return out
+
+
+def wav_header_streaming() -> bytes:
+    """audio.WriteWAVHeaderStreaming (wav_stream.go:15-41)."""
+    buf = (C.c_uint8 * 44)()
+    L = lib()
+    L.po_wav_header_streaming.argtypes = [C.c_void_p]
+    L.po_wav_header_streaming.restype = None
+    L.po_wav_header_streaming(buf)
+    return bytes(buf)

@@ -1321,3 +1321,36 @@ int po_generate(const po_model* m, const po_request* rq, po_result* res, char* e
 }
 
 void po_free_result(po_result* r) { if (!r) return; free(r->pcm); free(r->latents); r->pcm = NULL; r->latents = NULL; }
+
+/* ---- PCM egress: internal/audio/wav_stream.go ---- */
+/* WritePCM16Samples (:43-54): clamped := math.Max(-1, math.Min(1, float64(s))); v := int16(clamped * 32767).
+ * The product is exact in float64 (24-bit x 15-bit), the conversion truncates toward zero.  A NaN passes through
+ * Min/Max; Go's float64 -> int16 of NaN is CVTTSD2SQ's 0x8000000000000000 truncated to 16 bits on amd64: 0. */
+void po_pcm16(const float* s, int64_t n, int16_t* out) {
+    for (int64_t i = 0; i < n; i++) {
+        double c = (double)s[i];
+        if (c != c) { out[i] = 0; continue; }
+        if (c > 1.0) c = 1.0;
+        if (c < -1.0) c = -1.0;
+        out[i] = (int16_t)(c * 32767.0);
+    }
+}
+
+/* WriteWAVHeaderStreaming (:15-41): 44 bytes, 24 kHz mono 16-bit PCM, RIFF and data sizes 0xFFFFFFFF */
+void po_wav_header_streaming(uint8_t out[44]) {
+    const uint32_t rate = 24000, byte_rate = 24000 * 1 * 16 / 8;
+    const uint16_t channels = 1, bits = 16, block_align = 2;
+    memcpy(out + 0, "RIFF", 4);
+    out[4] = out[5] = out[6] = out[7] = 0xFF;
+    memcpy(out + 8, "WAVE", 4);
+    memcpy(out + 12, "fmt ", 4);
+    out[16] = 16; out[17] = out[18] = out[19] = 0;
+    out[20] = 1; out[21] = 0;
+    out[22] = (uint8_t)channels; out[23] = 0;
+    out[24] = (uint8_t)(rate & 0xFF); out[25] = (uint8_t)((rate >> 8) & 0xFF); out[26] = (uint8_t)((rate >> 16) & 0xFF); out[27] = (uint8_t)(rate >> 24);
+    out[28] = (uint8_t)(byte_rate & 0xFF); out[29] = (uint8_t)((byte_rate >> 8) & 0xFF); out[30] = (uint8_t)((byte_rate >> 16) & 0xFF); out[31] = (uint8_t)(byte_rate >> 24);
+    out[32] = (uint8_t)block_align; out[33] = 0;
+    out[34] = (uint8_t)bits; out[35] = 0;
+    memcpy(out + 36, "data", 4);
+    out[40] = out[41] = out[42] = out[43] = 0xFF;
+}

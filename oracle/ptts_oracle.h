@@ -73,6 +73,9 @@ void po_silu(float* x, int64_t n);               /* tensor_util.go:73-82 */
 void po_elu(float* x, int64_t n);                /* tensor_util.go:119-128 */
 int  po_rmsnorm_alpha(float* x, const float* alpha, float eps, int64_t outer, int64_t d); /* :273-326 */
 void po_replace_nan(float* x, int64_t n, const float* vec, int64_t d);  /* :242-271 */
+/* PCM egress: internal/audio/wav_stream.go:43-54 WritePCM16Samples and :15-41 WriteWAVHeaderStreaming */
+void po_pcm16(const float* s, int64_t n, int16_t* out);
+void po_wav_header_streaming(uint8_t out[44]);
 int  po_denorm_latent_to_bct(const float* latent, const float* std, const float* mean,
                              int64_t b, int64_t t, int64_t d, float* out); /* model.go:349-407 */
 int  po_split_voice_kv(const float* cache, int64_t b, int64_t steps, int64_t heads, int64_t hd,

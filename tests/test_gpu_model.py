@@ -417,3 +417,19 @@ def test_two_phase_open_adopts_prefilled_arena(pkg, tiny):
     assert np.array_equal(a.pcm, b.pcm) and np.array_equal(a.pcm, c.pcm)
     m1.close()
     m2.close()
+
+
+def test_pcm16_egress_is_the_reference_encoding_of_the_f32_result(pkg, tiny):
+    """PCM16 produced on the device == audio.WritePCM16Samples (oracle) applied to the f32 PCM the same
+    request returns (the generation is deterministic, so the two runs see identical samples): bit-exact, incl. clamping."""
+    _, _, om, gm = tiny
+    toks = [np.array([10, 20, 30], np.int64), np.array([5, 6, 7, 8, 9], np.int64)]
+    mk = lambda s16: [pkg.RuntimeGenerateConfig(max_steps=3, eos_threshold=1e30, pcm16=s16) for _ in toks]
+    f32 = gm.generate_batch(toks, mk(False))
+    s16 = gm.generate_batch(toks, mk(True))
+    for a, b in zip(f32, s16):
+        assert b.pcm.dtype == np.int16 and b.pcm.shape == a.pcm.shape and b.n_frames == a.n_frames
+        loud = a.pcm * np.float32(40.0)   # the tiny synthetic model is quiet: also check the encoder away from zero and in the clamp
+        assert np.array_equal(b.pcm, O.pcm16(a.pcm))
+        assert np.abs(O.pcm16(loud)).max() > 0
+    assert pkg.runtime.wav_header_streaming() == O.wav_header_streaming()

@@ -174,3 +174,13 @@ def test_convtr_depthwise_random_vs_oracle(R):
     x = rng.standard_normal((2, 512, 5)).astype(np.float32)
     w = rng.standard_normal((512, 1, 32)).astype(np.float32)
     close(R.op_convtr1d_righttrim(x, w, None, 16, 512), O.convtr1d(x, w, None, 16, 0, 0, 1, 512, 16), TOL["convtranspose1d"], TOL["convtranspose1d"])
+
+
+@pytest.mark.parametrize("n", [1, 7, 8, 9, 1000, 4099])
+def test_pcm16_kernel_is_bit_exact(pkg, n):
+    """wav_stream.go:43-54 on the device against the oracle: clamp, exact float64 product, truncation, NaN/inf, ragged tails."""
+    rng = np.random.default_rng(n)
+    x = (rng.standard_normal(n) * 0.7).astype(np.float32)
+    special = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 2.0, -3.0, np.nan, np.inf, -np.inf, 0.99999, -0.99999, 3.0517578e-05, -3.0517578e-05], np.float32)
+    x[: min(n, special.size)] = special[: min(n, special.size)]
+    assert np.array_equal(pkg.runtime.op_pcm16(x), O.pcm16(x))

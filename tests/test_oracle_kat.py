@@ -310,3 +310,28 @@ def test_prepare_chunks_upstream_cases():
         assert TP.frames_after_eos(chunks[0]["num_words"]) > 0
     with pytest.raises(ValueError):
         TP.prepare_chunks("   ", enc, 50)
+
+
+@pytest.mark.parametrize("name", ["pcm16_encoding", "pcm16_clamping"])
+def test_pcm16(name):
+    """audio/wav_stream_test.go:106-149: clamp to [-1, 1], * 32767, truncation; the reference's own tolerance is 1 LSB."""
+    c = KAT[name]
+    got = O.pcm16(np.array(c["samples"], np.float32))
+    assert np.abs(got.astype(np.int32) - np.array(c["want"], np.int32)).max() <= c["tol_lsb"]
+
+
+def test_pcm16_truncates_toward_zero_and_maps_nan_to_zero():
+    x = np.array([0.99999, -0.99999, 1e-5, -1e-5, np.nan, np.inf, -np.inf, 0.25], np.float32)
+    want = [int(np.trunc(np.float64(v) * 32767.0)) if np.isfinite(v) else (0 if np.isnan(v) else int(np.sign(v)) * 32767) for v in x]
+    assert O.pcm16(x).tolist() == want
+
+
+def test_wav_header_streaming():
+    c = KAT["wav_header_streaming"]
+    h = O.wav_header_streaming()
+    assert len(h) == c["len"]
+    assert h[0:4] == c["riff"].encode() and h[8:12] == c["wave"].encode() and h[12:16] == c["fmt"].encode() and h[36:40] == c["data"].encode()
+    u32 = lambda o: int.from_bytes(h[o:o + 4], "little")
+    u16 = lambda o: int.from_bytes(h[o:o + 2], "little")
+    assert u32(4) == c["riff_size"] and u32(40) == c["data_size"] and u32(16) == c["fmt_size"]
+    assert (u16(20), u16(22), u32(24), u32(28), u16(32), u16(34)) == (c["format"], c["channels"], c["sample_rate"], c["byte_rate"], c["block_align"], c["bits"])
