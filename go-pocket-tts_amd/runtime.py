@@ -285,7 +285,7 @@ class Model:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():   # the HIP runtime may already be gone at interpreter teardown
+        if sys is None or sys.is_finalizing():   # the HIP runtime may already be gone at interpreter teardown
             return
         try:
             self.close()
@@ -402,7 +402,7 @@ class DeviceVoice:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():
+        if sys is None or sys.is_finalizing():
             return
         try:
             self.close()
@@ -455,7 +455,7 @@ class Batch:
             self.h = None
 
     def __del__(self):
-        if sys.is_finalizing():   # the HIP runtime may already be gone at interpreter teardown
+        if sys is None or sys.is_finalizing():   # the HIP runtime may already be gone at interpreter teardown
             return
         try:
             self.close()
