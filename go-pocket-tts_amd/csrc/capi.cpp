@@ -521,7 +521,7 @@ int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, in
         SkinnyFuse fu;
         if (fuse_ln) { fu.ln = 1; fu.ln_w = dlnw.as<float>(); fu.ln_b = dlnw.as<float>(); }
         if (!(fuse_ln ? skinny_fuse_supported(g, fu) : skinny_supported(g, splitk))) throw Error(PTTS_EINVAL, "shape not supported");
-        const int blocks = ((N + 63) / 64) * ((M + 15) / 16) * (splitk > 1 ? splitk : 1);
+        const int blocks = ((N + 15) / 16) * ((M + 15) / 16) * (splitk > 1 ? splitk : 1);   // upper bound: the narrow-block variant has N/16 column blocks
         Tmp dS((size_t)blocks * 8 * 8);
         PTTS_HIP(hipMemset(dS.p, 0, (size_t)blocks * 64));
         for (int i = 0; i < 3; i++) launch_skinny(g, fu, splitk, dC.as<float>(), nullptr);

@@ -55,7 +55,10 @@ union Frag8 {
 // prologue variants (template parameter PRO)
 constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8;
 
-template <bool WBF16, bool STAMP, int PRO, int NJ>   // NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024)
+// NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024).
+// CG: 16-column groups per block (4: 64 columns x 4 K parts; 1: 16 columns x 16 K parts -- four times the blocks, for
+// launches whose 64-column grid would leave most of the chip idle: batch <= 16, the reference's own batch-1 case)
+template <bool WBF16, bool STAMP, int PRO, int NJ, int CG>
 __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_m, int p_n, int p_k, int splitk, GemmArgs a, SkinnyFuse fu,
                                                  float* partial, unsigned long long* stamps) {
     // The seven leading scalars (copies of a.Wt, a.A, a.amap.ld, a.M, a.N, a.K, and the split) are what the weight and
@@ -71,15 +74,16 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     __shared__ __attribute__((aligned(16))) unsigned char Xh[16 * 2048];
     __shared__ __attribute__((aligned(16))) unsigned char Xl[16 * 2048];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches
-    const int cg = wave & 3, kq4 = wave >> 2;
-    const int n = blockIdx.x * 64 + cg * 16 + (lane & 15);
+    constexpr int KP = 16 / CG;                // K parts per column group
+    const int cg = wave % CG, kq4 = wave / CG;
+    const int n = blockIdx.x * (16 * CG) + cg * 16 + (lane & 15);
     const int m0 = blockIdx.y * 16, z = blockIdx.z, q = lane >> 4;
     const bool n_ok = n < p_n;
     const int kper = splitk > 1 ? ((p_k + splitk - 1) / splitk + 127) / 128 * 128 : p_k;
     const int k_begin = z * kper, k_end = min(p_k, k_begin + kper);
     const int klen = k_end - k_begin;          // <= SK_KMAX (host guarantees)
     const int nss = (klen + 127) >> 7;         // 128-deep super-steps in the slice (<= 8)
-    const int ssq = (nss + 3) >> 2;            // super-steps per K quarter (<= 2)
+    const int ssq = (nss + KP - 1) / KP;       // super-steps per K part (<= NTW)
     const int ss_lo = kq4 * ssq;
 
     // ---- weights: everything this wave will multiply is requested now ----
@@ -87,11 +91,11 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     // wave-instruction.  The loads are unconditional (a tile / super-step that does not exist re-reads block 0 and is never
     // multiplied or stored): a load under a condition becomes a branch, and the compiler then drains the memory pipe
     // (s_waitcnt vmcnt(0)) between the weight loads.
-    constexpr int NTW = NJ / 2;   // super-steps per K quarter
+    constexpr int NTW = (2 * NJ + KP - 1) / KP;   // super-steps per K part: the slice has at most 2 NJ of them
     uint4 w[NTW][WV];
     {
         const int nss_all = (p_k + 127) >> 7;
-        const int tile = blockIdx.x * 4 + cg, ss_base = k_begin >> 7;
+        const int tile = blockIdx.x * CG + cg, ss_base = k_begin >> 7;
         const bool tile_ok = tile * 16 < p_n;
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -295,14 +299,14 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     __syncthreads();
     float4* red = reinterpret_cast<float4*>(Xh);   // [kq4][cg][lane]
     const f32x4 accv = acc_h + acc_l;
-    if (kq4 > 0) red[(kq4 * 4 + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
+    if (kq4 > 0) red[(kq4 * CG + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
     __syncthreads();
     SK_STAMP(5);
     if (kq4 > 0 || !n_ok) return;
     float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
 #pragma unroll
-    for (int t = 1; t < 4; t++) {
-        float4 p = red[(t * 4 + cg) * 64 + lane];
+    for (int t = 1; t < KP; t++) {
+        float4 p = red[(t * CG + cg) * 64 + lane];
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
     }
     // D layout of 16x16x32: column (n) = lane & 15, row (m) = (lane >> 4) * 4 + reg
@@ -353,10 +357,19 @@ bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
 
 unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_stamps)
 
+template <bool WBF16, int PRO, int NJ, int CG>
+static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
+    dim3 grid((a.N + 16 * CG - 1) / (16 * CG), (a.M + 15) / 16, splitk);
+    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, g_skinny_stamps);
+    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
+}
+
 template <bool WBF16, int PRO, int NJ>
-static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
-    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, g_skinny_stamps);
-    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
+static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 /*grid*/, hipStream_t stream) {
+    // narrow blocks when the 64-column grid would occupy fewer than half of the 256 CUs
+    const int blocks64 = ((a.N + 63) / 64) * ((a.M + 15) / 16) * splitk;
+    if (blocks64 < 128 && a.N > 16) launch_cg<WBF16, PRO, NJ, 1>(a, fu, splitk, partial, stream);
+    else launch_cg<WBF16, PRO, NJ, 4>(a, fu, splitk, partial, stream);
 }
 
 template <bool WBF16, int PRO>
