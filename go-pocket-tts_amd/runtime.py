@@ -205,6 +205,21 @@ class RuntimeGenerateConfig:
     pcm16: bool = False   # PCM egress on the device: GenerateResult.pcm is int16 = audio.WritePCM16Samples (wav_stream.go:43-54)
 
 
+class _OwnedBuffer:
+    """A result buffer handed over by the library: exposes it to numpy without a copy and frees it on collection."""
+
+    def __init__(self, ptr, n: int, typestr: str):
+        self._addr = C.cast(ptr, C.c_void_p).value
+        self.__array_interface__ = {"shape": (n,), "typestr": typestr, "data": (self._addr, False), "version": 3}
+
+    def __del__(self):
+        if self._addr and sys is not None and not sys.is_finalizing():
+            r = _Result()
+            r.pcm = C.cast(C.c_void_p(self._addr), _FP)
+            lib().ptts_free_result(C.byref(r))
+            self._addr = None
+
+
 @dataclass
 class GenerateResult:
     pcm: np.ndarray
@@ -378,10 +393,17 @@ class Model:
             _check(rc)
             for i in range(n):
                 rs = ress[i]
-                if getattr(cfgs[i], "pcm16", False):   # PCM16 egress: int16 samples encoded on the device
-                    pcm = np.ctypeslib.as_array(rs.pcm16, (rs.n_samples,)).copy() if rs.n_samples else np.zeros(0, np.int16)
+                s16 = bool(getattr(cfgs[i], "pcm16", False))   # PCM16 egress: int16 samples encoded on the device
+                if rs.n_samples:
+                    # zero-copy: the array views the library's (page-locked) result buffer and gives it back to the pool
+                    # when it is garbage-collected
+                    pcm = np.asarray(_OwnedBuffer(rs.pcm16 if s16 else rs.pcm, int(rs.n_samples), "<i2" if s16 else "<f4"))
+                    if s16:
+                        rs.pcm16 = None
+                    else:
+                        rs.pcm = None
                 else:
-                    pcm = np.ctypeslib.as_array(rs.pcm, (rs.n_samples,)).copy() if rs.n_samples else np.zeros(0, np.float32)
+                    pcm = np.zeros(0, np.int16 if s16 else np.float32)
                 lat = None
                 if cfgs[i].want_latents:
                     lat = np.ctypeslib.as_array(rs.latents, (rs.n_frames, self.info.ldim)).copy()
