@@ -185,6 +185,46 @@ void ptts_free_result(ptts_result* r) {
     r->n_frames = 0;
 }
 
+struct ptts_dispatcher { Dispatcher* d; };
+
+int ptts_dispatcher_create(ptts_model* const* models, int32_t n_models, const ptts_dispatch_opts* o, ptts_dispatcher** out) {
+    return guard([&] {
+        if (!models || n_models <= 0 || !out) throw Error(PTTS_EINVAL, "dispatcher: at least one model is required");
+        std::vector<Model*> ms;
+        for (int i = 0; i < n_models; i++) {
+            if (!models[i] || !models[i]->m) throw Error(PTTS_EINVAL, "dispatcher: nil model");
+            ms.push_back(models[i]->m);
+        }
+        *out = new ptts_dispatcher{dispatcher_create(ms.data(), n_models, nullptr, nullptr, 0, o ? o->max_batch : 0, o ? o->window_us : 2000, o ? o->queue_cap : 0)};
+    });
+}
+
+int ptts_dispatcher_create_custom(ptts_dispatch_exec exec, void* user, int32_t n_workers, const ptts_dispatch_opts* o, ptts_dispatcher** out) {
+    return guard([&] {
+        if (!exec || !out) throw Error(PTTS_EINVAL, "dispatcher: nil executor");
+        *out = new ptts_dispatcher{dispatcher_create(nullptr, 0, exec, user, n_workers, o ? o->max_batch : 0, o ? o->window_us : 2000, o ? o->queue_cap : 0)};
+    });
+}
+
+int ptts_dispatch_generate(ptts_dispatcher* d, const ptts_request* req, ptts_result* result) {
+    return guard([&] {
+        if (!d || !d->d || !req || !result) throw Error(PTTS_EINVAL, "dispatcher: nil argument");
+        std::string err;
+        const int rc = dispatcher_generate(d->d, req, result, &err);
+        if (rc != PTTS_OK) throw Error(rc, err.empty() ? "generate: request failed" : err);
+    });
+}
+
+void ptts_dispatcher_stats(ptts_dispatcher* d, ptts_dispatch_stats* out) {
+    if (d && d->d && out) dispatcher_stats(d->d, out);
+}
+
+void ptts_dispatcher_close(ptts_dispatcher* d) {
+    if (!d) return;
+    dispatcher_close(d->d);
+    delete d;
+}
+
 void ptts_wav_header_streaming(uint8_t out[44]) {   // internal/audio/wav_stream.go:15-41
     static const uint8_t hdr[44] = {'R', 'I', 'F', 'F', 0xFF, 0xFF, 0xFF, 0xFF, 'W', 'A', 'V', 'E', 'f', 'm', 't', ' ', 16, 0, 0, 0, 1, 0, 1, 0,
                                     0xC0, 0x5D, 0, 0 /* 24000 */, 0x80, 0xBB, 0, 0 /* 48000 B/s */, 2, 0, 16, 0, 'd', 'a', 't', 'a', 0xFF, 0xFF, 0xFF, 0xFF};

@@ -1,0 +1,210 @@
+// dispatcher.cpp -- SURVEY.md 8f N1: what the reference's worker pool becomes in front of a batching GPU runtime.
+//
+// The reference admits `workers` (default 2) concurrent Synthesize calls through a channel semaphore and lets the rest wait
+// (internal/server/server.go:132-134,398-421); each admitted call then runs its chunks one by one, and the native runtime
+// serialises the AR steps of concurrent calls on a mutex (runtime_native_safetensors.go:161-170).  On the GPU a step costs
+// the same for 1 or 64 utterances, so the unit of admission is a BATCH: callers block in ptts_dispatch_generate, a worker
+// thread per model (one model per GPU) takes the oldest waiting request, keeps collecting for at most `window_us` (or until
+// `max_batch`), runs ONE ptts_generate-equivalent for the lot and wakes each caller with its own result.  A request whose
+// cancel flag is raised while it waits is answered PTTS_ECANCELLED without running, the counterpart of "request cancelled
+// while waiting for worker" (server.go:415-418).  Utterance chunks are independent, so nothing is exchanged between GPUs:
+// several models simply pull from the same queue.
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <thread>
+
+#include "runtime.h"
+
+namespace ptts {
+
+const std::string& last_error_ref();
+
+using Clock = std::chrono::steady_clock;
+
+struct DispatchItem {
+    const ptts_request* req = nullptr;
+    ptts_result* res = nullptr;
+    const Model* pinned = nullptr;      // a device-resident voice ties the request to the model (GPU) that holds it
+    Clock::time_point enq;
+    int rc = PTTS_OK;
+    std::string err;
+    bool done = false;
+    std::condition_variable cv;
+};
+
+struct Dispatcher {
+    std::vector<Model*> models;         // empty for a custom executor (CPU tests of the queueing logic)
+    ExecFn exec = nullptr;
+    void* exec_user = nullptr;
+    int n_workers = 0;
+    int max_batch = 64;
+    int window_us = 2000;
+    int queue_cap = 4096;
+    std::mutex mu;
+    std::condition_variable cv_work;
+    std::deque<DispatchItem*> queue;
+    bool closing = false;
+    std::vector<std::thread> workers;
+    // statistics
+    int64_t n_requests = 0, n_batches = 0, n_cancelled_waiting = 0, max_depth = 0;
+    double sum_wait_us = 0.0, sum_exec_us = 0.0;
+
+    void run(int w);
+};
+
+static bool cancelled(const DispatchItem* it) { return it->req->cancel && *it->req->cancel; }
+
+void Dispatcher::run(int w) {
+    Model* model = models.empty() ? nullptr : models[(size_t)w];
+    if (model) model->use_device();
+    for (;;) {
+        std::vector<DispatchItem*> batch;
+        {
+            std::unique_lock<std::mutex> lock(mu);
+            auto eligible = [&](const DispatchItem* it) { return !it->pinned || it->pinned == model; };
+            auto first = [&]() -> DispatchItem* {
+                for (DispatchItem* it : queue) if (eligible(it)) return it;
+                return nullptr;
+            };
+            cv_work.wait(lock, [&] { return closing || first() != nullptr; });
+            if (closing && first() == nullptr) return;
+            // coalescing window: counted from the moment the oldest eligible request arrived, so a lone request waits at
+            // most window_us and a full batch leaves at once
+            const Clock::time_point deadline = first()->enq + std::chrono::microseconds(window_us);
+            auto n_eligible = [&] { int n = 0; for (DispatchItem* it : queue) n += eligible(it); return n; };
+            while (!closing && n_eligible() < max_batch && Clock::now() < deadline) cv_work.wait_until(lock, deadline);
+            const Clock::time_point now = Clock::now();
+            for (auto it = queue.begin(); it != queue.end() && (int)batch.size() < max_batch;) {
+                DispatchItem* d = *it;
+                if (!eligible(d)) { ++it; continue; }
+                it = queue.erase(it);
+                if (cancelled(d)) {   // never ran: the reference answers 503 "request cancelled while waiting for worker"
+                    d->rc = PTTS_ECANCELLED;
+                    d->err = "request cancelled while waiting for worker";
+                    d->done = true;
+                    n_cancelled_waiting++;
+                    d->cv.notify_one();
+                    continue;
+                }
+                sum_wait_us += std::chrono::duration<double, std::micro>(now - d->enq).count();
+                batch.push_back(d);
+            }
+            if (batch.empty()) continue;
+            n_batches++;
+            n_requests += (int64_t)batch.size();
+        }
+        std::vector<ptts_request> reqs(batch.size());
+        std::vector<ptts_result> ress(batch.size());
+        for (size_t i = 0; i < batch.size(); i++) reqs[i] = *batch[i]->req;
+        std::string err;
+        int rc = PTTS_OK;
+        const Clock::time_point t0 = Clock::now();
+        if (exec) {
+            char buf[256] = {0};
+            for (auto& r : ress) { std::memset(&r, 0, sizeof r); r.eos_step = -1; }
+            rc = exec(exec_user, w, reqs.data(), (int32_t)reqs.size(), ress.data(), buf, (int32_t)sizeof buf);
+            err = buf;
+        } else {
+            try {
+                set_last_error("");
+                generate(*model, reqs.data(), (int)reqs.size(), ress.data());
+                err = last_error_ref();
+            } catch (const Error& e) {
+                rc = e.code; err = e.what();
+            } catch (const std::exception& e) {
+                rc = PTTS_EINVAL; err = std::string("ptts-hip: ") + e.what();
+            }
+        }
+        const double exec_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count();
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            sum_exec_us += exec_us;
+            for (size_t i = 0; i < batch.size(); i++) {
+                DispatchItem* d = batch[i];
+                *d->res = ress[i];
+                d->rc = rc != PTTS_OK ? rc : ress[i].status;
+                if (d->rc != PTTS_OK) d->err = err.empty() ? "generate: request failed" : err;
+                d->done = true;
+                d->cv.notify_one();
+            }
+        }
+    }
+}
+
+Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, void* user, int n_workers, int max_batch, int window_us, int queue_cap) {
+    std::unique_ptr<Dispatcher> d(new Dispatcher());
+    if (exec) {
+        d->exec = exec; d->exec_user = user; d->n_workers = std::max(1, n_workers);
+    } else {
+        if (n_models <= 0 || !models) throw Error(PTTS_EINVAL, "dispatcher: at least one model is required");
+        for (int i = 0; i < n_models; i++) {
+            if (!models[i]) throw Error(PTTS_EINVAL, "dispatcher: nil model");
+            d->models.push_back(models[i]);
+        }
+        d->n_workers = n_models;
+        if (max_batch <= 0) max_batch = models[0]->opts.max_batch;
+    }
+    d->max_batch = std::max(1, max_batch <= 0 ? 64 : max_batch);
+    d->window_us = std::max(0, window_us);
+    d->queue_cap = queue_cap <= 0 ? 4096 : queue_cap;
+    for (int w = 0; w < d->n_workers; w++) d->workers.emplace_back([p = d.get(), w] { p->run(w); });
+    return d.release();
+}
+
+void dispatcher_close(Dispatcher* d) {
+    if (!d) return;
+    {
+        std::lock_guard<std::mutex> lock(d->mu);
+        d->closing = true;
+    }
+    d->cv_work.notify_all();
+    for (auto& t : d->workers) t.join();
+    {   // whatever is still queued (only possible for requests pinned to no live worker) is refused
+        std::lock_guard<std::mutex> lock(d->mu);
+        for (DispatchItem* it : d->queue) { it->rc = PTTS_ECANCELLED; it->err = "dispatcher closed"; it->done = true; it->cv.notify_one(); }
+        d->queue.clear();
+    }
+    delete d;
+}
+
+int dispatcher_generate(Dispatcher* d, const ptts_request* req, ptts_result* res, std::string* err) {
+    std::memset(res, 0, sizeof *res);
+    res->eos_step = -1;
+    DispatchItem item;
+    item.req = req; item.res = res;
+    if (!d->models.empty()) {
+        std::string e = request_error(d->models[0]->d, *req);   // refuse malformed requests before they cost a batch slot
+        if (!e.empty()) { *err = e; res->status = PTTS_EINVAL; return PTTS_EINVAL; }
+        if (req->voice) {
+            item.pinned = reinterpret_cast<const Voice*>(req->voice)->m;
+            bool served = false;
+            for (Model* m : d->models) served |= m == item.pinned;
+            if (!served) { *err = "ptts-hip: voice belongs to a model this dispatcher does not serve"; res->status = PTTS_EINVAL; return PTTS_EINVAL; }
+        }
+    }
+    std::unique_lock<std::mutex> lock(d->mu);
+    if (d->closing) { *err = "dispatcher closed"; res->status = PTTS_ECANCELLED; return PTTS_ECANCELLED; }
+    if ((int)d->queue.size() >= d->queue_cap) { *err = "dispatcher: queue full"; res->status = PTTS_ENOMEM; return PTTS_ENOMEM; }
+    item.enq = Clock::now();
+    d->queue.push_back(&item);
+    d->max_depth = std::max<int64_t>(d->max_depth, (int64_t)d->queue.size());
+    d->cv_work.notify_all();
+    item.cv.wait(lock, [&] { return item.done; });
+    if (item.rc != PTTS_OK) *err = item.err;
+    return item.rc;
+}
+
+void dispatcher_stats(Dispatcher* d, ptts_dispatch_stats* out) {
+    std::lock_guard<std::mutex> lock(d->mu);
+    std::memset(out, 0, sizeof *out);
+    out->requests = d->n_requests;
+    out->batches = d->n_batches;
+    out->cancelled_waiting = d->n_cancelled_waiting;
+    out->max_queue_depth = d->max_depth;
+    out->mean_batch = d->n_batches ? (double)d->n_requests / (double)d->n_batches : 0.0;
+    out->mean_wait_us = d->n_requests ? d->sum_wait_us / (double)d->n_requests : 0.0;
+    out->mean_exec_us = d->n_batches ? d->sum_exec_us / (double)d->n_batches : 0.0;
+}
+
+}  // namespace ptts

@@ -1042,6 +1042,16 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     }
 }
 
+std::string request_error(const Desc& d, const ptts_request& q) {   // the argument checks of GenerateAudio (runtime_native_safetensors.go:52-119)
+    if (!q.tokens || q.n_tokens <= 0) return "generate: token slice must not be empty";
+    if ((q.voice_embedding != nullptr) + (q.voice_caches != nullptr) + (q.voice != nullptr) > 1) return "generate: voice embedding and voice model state are mutually exclusive";
+    if (q.voice_caches && (!q.voice_cache_steps || !q.voice_offsets)) return "generate: load voice model state: missing cache steps/offsets";
+    for (int64_t t = 0; t < q.n_tokens; t++)
+        if (q.tokens[t] < 0 || q.tokens[t] >= d.n_bins)
+            return strfmt("generate: text embeddings: native: token id %lld (%lld) out of range [0,%d)", (long long)t, (long long)q.tokens[t], d.n_bins);
+    return std::string();
+}
+
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res) {
     std::lock_guard<std::mutex> lock(m.mu);
     m.use_device();
@@ -1053,17 +1063,7 @@ void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res) {
         std::memset(&r, 0, sizeof r);
         r.eos_step = -1;
         const ptts_request& q = reqs[i];
-        std::string err;
-        if (!q.tokens || q.n_tokens <= 0) err = "generate: token slice must not be empty";
-        else if ((q.voice_embedding != nullptr) + (q.voice_caches != nullptr) + (q.voice != nullptr) > 1) err = "generate: voice embedding and voice model state are mutually exclusive";
-        else if (q.voice_caches && (!q.voice_cache_steps || !q.voice_offsets)) err = "generate: load voice model state: missing cache steps/offsets";
-        else {
-            for (int64_t t = 0; t < q.n_tokens; t++)
-                if (q.tokens[t] < 0 || q.tokens[t] >= d.n_bins) {
-                    err = strfmt("generate: text embeddings: native: token id %lld (%lld) out of range [0,%d)", (long long)t, (long long)q.tokens[t], d.n_bins);
-                    break;
-                }
-        }
+        std::string err = request_error(d, q);
         if (!err.empty()) {
             r.status = PTTS_EINVAL;
             if (first_err.empty()) first_err = err;

@@ -136,5 +136,15 @@ void step_core(Batch& b, int lsd_steps, bool opened = false);   // opened: x and
 void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev);
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
+std::string request_error(const Desc& d, const ptts_request& q);   // empty: the request is well formed
+
+
+// request dispatcher (dispatcher.cpp)
+struct Dispatcher;
+typedef int (*ExecFn)(void* user, int worker, const ptts_request* reqs, int32_t n, ptts_result* results, char* err, int32_t errlen);
+Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, void* user, int n_workers, int max_batch, int window_us, int queue_cap);
+void dispatcher_close(Dispatcher* d);
+int dispatcher_generate(Dispatcher* d, const ptts_request* req, ptts_result* res, std::string* err);
+void dispatcher_stats(Dispatcher* d, ptts_dispatch_stats* out);
 
 }  // namespace ptts

@@ -83,6 +83,7 @@ ABI_SYMBOLS = [
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
+    "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
 ]
 
 
@@ -352,62 +353,66 @@ class Model:
         return out
 
     # -- batched GenerateAudio
+    def _fill_request(self, r, toks, cfg, keep):
+        t = np.ascontiguousarray(toks, np.int64)
+        keep.append(t)
+        r.tokens, r.n_tokens = _ip(t), t.size
+        r.temperature, r.eos_threshold = cfg.temperature, min(cfg.eos_threshold, 3.0e38)
+        r.max_steps, r.estimated_max_steps = cfg.max_steps, cfg.estimated_max_steps
+        r.lsd_steps, r.frames_after_eos = cfg.lsd_decode_steps, cfg.frames_after_eos
+        if cfg.voice_embedding is not None:
+            ve = _f32(cfg.voice_embedding.data).reshape(-1, self.info.d_model)
+            keep.append(ve)
+            r.voice_embedding, r.voice_frames = _fp(ve), ve.shape[0]
+        if cfg.voice_model_state is not None:
+            ptrs, steps, offs, arrs = _voice_arrays(cfg.voice_model_state, self.info.n_layers)
+            keep += [ptrs, steps, offs, arrs]
+            r.voice_caches, r.voice_cache_steps, r.voice_offsets = ptrs, _ip(steps), _ip(offs)
+        if cfg.device_voice is not None:
+            r.voice = cfg.device_voice.h
+        if cfg.noise is not None:
+            nz = _f32(cfg.noise).reshape(-1, self.info.ldim)
+            keep.append(nz)
+            r.noise = _fp(nz)
+        if cfg.step_callback is not None:
+            cb = _STEP_CB(lambda _u, s, m, f=cfg.step_callback: f(s, m))
+            keep.append(cb)
+            r.step_callback = cb
+        if cfg.cancel is not None:
+            r.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
+        r.want_latents = 1 if cfg.want_latents else 0
+        r.pcm_format = 1 if getattr(cfg, "pcm16", False) else 0
+
+    def _take_result(self, rs, cfg) -> "GenerateResult":
+        s16 = bool(getattr(cfg, "pcm16", False))   # PCM16 egress: int16 samples encoded on the device
+        if rs.n_samples:
+            # zero-copy: the array views the library's (page-locked) result buffer and gives it back to the pool
+            # when it is garbage-collected
+            pcm = np.asarray(_OwnedBuffer(rs.pcm16 if s16 else rs.pcm, int(rs.n_samples), "<i2" if s16 else "<f4"))
+            if s16:
+                rs.pcm16 = None
+            else:
+                rs.pcm = None
+        else:
+            pcm = np.zeros(0, np.int16 if s16 else np.float32)
+        lat = None
+        if cfg.want_latents:
+            lat = np.ctypeslib.as_array(rs.latents, (rs.n_frames, self.info.ldim)).copy()
+        return GenerateResult(pcm, int(rs.n_frames), int(rs.eos_step), lat)
+
     def generate_batch(self, token_lists: Sequence[Sequence[int]], cfgs: Sequence[RuntimeGenerateConfig]) -> list[GenerateResult]:
         n = len(token_lists)
         reqs = (_Request * n)()
         ress = (_Result * n)()
         keep = []
         for i, (toks, cfg) in enumerate(zip(token_lists, cfgs)):
-            t = np.ascontiguousarray(toks, np.int64)
-            keep.append(t)
-            r = reqs[i]
-            r.tokens, r.n_tokens = _ip(t), t.size
-            r.temperature, r.eos_threshold = cfg.temperature, min(cfg.eos_threshold, 3.0e38)
-            r.max_steps, r.estimated_max_steps = cfg.max_steps, cfg.estimated_max_steps
-            r.lsd_steps, r.frames_after_eos = cfg.lsd_decode_steps, cfg.frames_after_eos
-            if cfg.voice_embedding is not None:
-                ve = _f32(cfg.voice_embedding.data).reshape(-1, self.info.d_model)
-                keep.append(ve)
-                r.voice_embedding, r.voice_frames = _fp(ve), ve.shape[0]
-            if cfg.voice_model_state is not None:
-                ptrs, steps, offs, arrs = _voice_arrays(cfg.voice_model_state, self.info.n_layers)
-                keep += [ptrs, steps, offs, arrs]
-                r.voice_caches, r.voice_cache_steps, r.voice_offsets = ptrs, _ip(steps), _ip(offs)
-            if cfg.device_voice is not None:
-                r.voice = cfg.device_voice.h
-            if cfg.noise is not None:
-                nz = _f32(cfg.noise).reshape(-1, self.info.ldim)
-                keep.append(nz)
-                r.noise = _fp(nz)
-            if cfg.step_callback is not None:
-                cb = _STEP_CB(lambda _u, s, m, f=cfg.step_callback: f(s, m))
-                keep.append(cb)
-                r.step_callback = cb
-            if cfg.cancel is not None:
-                r.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
-            r.want_latents = 1 if cfg.want_latents else 0
-            r.pcm_format = 1 if getattr(cfg, "pcm16", False) else 0
+            self._fill_request(reqs[i], toks, cfg, keep)
         rc = lib().ptts_generate(self.h, reqs, n, ress)
         out = []
         try:
             _check(rc)
             for i in range(n):
-                rs = ress[i]
-                s16 = bool(getattr(cfgs[i], "pcm16", False))   # PCM16 egress: int16 samples encoded on the device
-                if rs.n_samples:
-                    # zero-copy: the array views the library's (page-locked) result buffer and gives it back to the pool
-                    # when it is garbage-collected
-                    pcm = np.asarray(_OwnedBuffer(rs.pcm16 if s16 else rs.pcm, int(rs.n_samples), "<i2" if s16 else "<f4"))
-                    if s16:
-                        rs.pcm16 = None
-                    else:
-                        rs.pcm = None
-                else:
-                    pcm = np.zeros(0, np.int16 if s16 else np.float32)
-                lat = None
-                if cfgs[i].want_latents:
-                    lat = np.ctypeslib.as_array(rs.latents, (rs.n_frames, self.info.ldim)).copy()
-                out.append(GenerateResult(pcm, int(rs.n_frames), int(rs.eos_step), lat))
+                out.append(self._take_result(ress[i], cfgs[i]))
         finally:
             for i in range(n):
                 lib().ptts_free_result(C.byref(ress[i]))
@@ -627,3 +632,74 @@ def op_pcm16(samples) -> np.ndarray:
     L.ptts_op_pcm16.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
     _check(L.ptts_op_pcm16(x.ctypes.data, x.size, out.ctypes.data))
     return out
+
+
+class _DispatchOpts(C.Structure):
+    _fields_ = [("max_batch", C.c_int32), ("window_us", C.c_int32), ("queue_cap", C.c_int32), ("reserved", C.c_int32 * 5)]
+
+
+class _DispatchStats(C.Structure):
+    _fields_ = [("requests", C.c_int64), ("batches", C.c_int64), ("cancelled_waiting", C.c_int64), ("max_queue_depth", C.c_int64),
+                ("mean_batch", C.c_double), ("mean_wait_us", C.c_double), ("mean_exec_us", C.c_double), ("reserved", C.c_int64 * 2)]
+
+
+DISPATCH_EXEC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(_Request), C.c_int32, C.POINTER(_Result), C.c_void_p, C.c_int32)
+
+
+class Dispatcher:
+    """The serving front of the runtime: `generate` blocks like Synthesize behind the reference's worker
+    semaphore (internal/server/server.go:398-421); concurrent callers are coalesced into batched GenerateAudio passes."""
+
+    def __init__(self, models: Sequence[Model], max_batch: int = 0, window_us: int = 2000, queue_cap: int = 0, _custom_exec=None, _workers: int = 1):
+        L = lib()
+        L.ptts_dispatcher_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(_DispatchOpts), C.POINTER(C.c_void_p)]
+        L.ptts_dispatcher_create_custom.argtypes = [DISPATCH_EXEC, C.c_void_p, C.c_int32, C.POINTER(_DispatchOpts), C.POINTER(C.c_void_p)]
+        L.ptts_dispatch_generate.argtypes = [C.c_void_p, C.POINTER(_Request), C.POINTER(_Result)]
+        L.ptts_dispatcher_stats.argtypes = [C.c_void_p, C.POINTER(_DispatchStats)]
+        L.ptts_dispatcher_close.argtypes = [C.c_void_p]
+        o = _DispatchOpts(max_batch=max_batch, window_us=window_us, queue_cap=queue_cap)
+        h = C.c_void_p()
+        self.models = list(models)
+        if _custom_exec is not None:
+            self._exec = DISPATCH_EXEC(_custom_exec)   # kept alive with the dispatcher
+            _check(L.ptts_dispatcher_create_custom(self._exec, None, _workers, C.byref(o), C.byref(h)))
+        else:
+            arr = (C.c_void_p * len(self.models))(*[m.h for m in self.models])
+            _check(L.ptts_dispatcher_create(arr, len(self.models), C.byref(o), C.byref(h)))
+        self.h = h.value
+
+    def generate(self, tokens: Sequence[int], cfg: RuntimeGenerateConfig) -> GenerateResult:
+        """Blocking; safe to call from many threads (the GIL is released while waiting)."""
+        req, res, keep = _Request(), _Result(), []
+        m = self.models[0] if self.models else None
+        if m is not None:
+            m._fill_request(req, tokens, cfg, keep)
+        else:   # custom executor (tests): only what the queueing logic looks at
+            t = np.ascontiguousarray(tokens, np.int64)
+            keep.append(t)
+            req.tokens, req.n_tokens = _ip(t), t.size
+            if cfg.cancel is not None:
+                req.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
+        rc = lib().ptts_dispatch_generate(self.h, C.byref(req), C.byref(res))
+        try:
+            _check(rc)
+            if m is None:
+                return GenerateResult(np.zeros(0, np.float32), int(res.n_frames), int(res.eos_step), None)
+            return m._take_result(res, cfg)
+        finally:
+            lib().ptts_free_result(C.byref(res))
+
+    def stats(self) -> dict:
+        s = _DispatchStats()
+        lib().ptts_dispatcher_stats(self.h, C.byref(s))
+        return {n: getattr(s, n) for n, _ in _DispatchStats._fields_ if n != "reserved"}
+
+    def close(self):
+        if self.h:
+            lib().ptts_dispatcher_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        self.close()

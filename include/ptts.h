@@ -143,6 +143,32 @@ void ptts_free_result(ptts_result* r);
  * 24 kHz, mono, 16 bit, RIFF and data sizes 0xFFFFFFFF. */
 void ptts_wav_header_streaming(uint8_t out[44]);
 
+/* ---- Request dispatcher (what the reference's worker pool becomes) ----------------------------------
+ * internal/server/server.go:132-134,398-421 admits `workers` concurrent Synthesize calls through a semaphore; here callers
+ * block in ptts_dispatch_generate and a worker thread per model coalesces waiting requests (up to max_batch, for at most
+ * window_us after the oldest one arrived) into one batched generate.  A request cancelled while it waits is answered
+ * PTTS_ECANCELLED without running.  Several models (one per GPU) pull from the same queue; nothing is exchanged between them.
+ * A request that carries a device voice is served by the model that voice was uploaded to. */
+typedef struct ptts_dispatcher ptts_dispatcher;
+typedef struct ptts_dispatch_opts {
+    int32_t max_batch;    /* <= 0: the model's max_batch */
+    int32_t window_us;    /* coalescing window, counted from the arrival of the oldest waiting request */
+    int32_t queue_cap;    /* <= 0: 4096; a full queue answers PTTS_ENOMEM */
+    int32_t reserved[5];
+} ptts_dispatch_opts;
+typedef struct ptts_dispatch_stats {
+    int64_t requests, batches, cancelled_waiting, max_queue_depth;
+    double  mean_batch, mean_wait_us, mean_exec_us;
+    int64_t reserved[2];
+} ptts_dispatch_stats;
+int  ptts_dispatcher_create(ptts_model* const* models, int32_t n_models, const ptts_dispatch_opts* opts, ptts_dispatcher** out);
+/* queueing logic over a caller-supplied executor (no GPU involved): unit tests of the coalescing / cancellation rules */
+typedef int (*ptts_dispatch_exec)(void* user, int32_t worker, const ptts_request* reqs, int32_t n, ptts_result* results, char* err, int32_t errlen);
+int  ptts_dispatcher_create_custom(ptts_dispatch_exec exec, void* user, int32_t n_workers, const ptts_dispatch_opts* opts, ptts_dispatcher** out);
+int  ptts_dispatch_generate(ptts_dispatcher* d, const ptts_request* req, ptts_result* result);   /* blocks until the request has run */
+void ptts_dispatcher_stats(ptts_dispatcher* d, ptts_dispatch_stats* out);
+void ptts_dispatcher_close(ptts_dispatcher* d);   /* waits for queued work; later calls are refused */
+
 /* Uploads a voice model state ([2,1,T,H,Dh] f32 per layer + offsets; safetensors.LoadVoiceModelState,
  * reader.go:127-140,273-308) once; requests then reference it by handle. */
 int  ptts_voice_create(ptts_model* m, const float* const* caches, const int64_t* cache_steps, const int64_t* offsets, ptts_voice** out);

@@ -433,3 +433,38 @@ def test_pcm16_egress_is_the_reference_encoding_of_the_f32_result(pkg, tiny):
         assert np.array_equal(b.pcm, O.pcm16(a.pcm))
         assert np.abs(O.pcm16(loud)).max() > 0
     assert pkg.runtime.wav_header_streaming() == O.wav_header_streaming()
+
+
+def test_dispatcher_coalesces_concurrent_callers_and_returns_each_its_own_audio(pkg, tiny):
+    """12 threads call Dispatcher.generate at once; the requests run as batches (max 8) and every caller gets
+    the audio a stand-alone GenerateAudio of its own request gives (same tolerance as the ragged-batch test: kernel
+    selection depends on the batch size)."""
+    import threading
+    _, _, om, gm = tiny
+    rng = np.random.default_rng(21)
+    prompts = [rng.integers(1, 60, size=int(rng.integers(3, 9))).astype(np.int64) for _ in range(12)]
+    steps = [int(rng.integers(2, 5)) for _ in range(12)]
+    cfg = lambda i: pkg.RuntimeGenerateConfig(max_steps=steps[i], eos_threshold=1e30, want_latents=True)
+    want = [gm.generate_batch([prompts[i]], [cfg(i)])[0] for i in range(12)]
+    d = pkg.Dispatcher([gm], max_batch=8, window_us=200_000)
+    got, errs = [None] * 12, [None] * 12
+
+    def client(i):
+        try:
+            got[i] = d.generate(prompts[i], cfg(i))
+        except Exception as e:  # noqa: BLE001
+            errs[i] = e
+
+    ts = [threading.Thread(target=client, args=(i,)) for i in range(12)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not any(errs), errs
+    st = d.stats()
+    assert st["requests"] == 12 and st["batches"] <= 4 and st["mean_batch"] >= 3.0
+    for i in range(12):
+        assert got[i].n_frames == want[i].n_frames == steps[i]
+        parity(f"dispatch latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
+        parity(f"dispatch pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
+    with pytest.raises(pkg.PttsError, match="token slice must not be empty"):
+        d.generate([], cfg(0))
+    d.close()

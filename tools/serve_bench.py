@@ -1,0 +1,55 @@
+"""Serving benchmark of the dispatcher: closed-loop clients, each synthesising 10-s utterances back to
+back through Dispatcher.generate; reports aggregate xRT, utterance latency and the batch sizes the dispatcher formed.
+
+    python tools/serve_bench.py [clients ...]        e.g.  python tools/serve_bench.py 1 8 64 128
+"""
+import os
+import statistics
+import sys
+import threading
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: F401  (one HIP runtime per process, see runtime.py lib())
+import bench
+import ptts_amd
+
+pkg = ptts_amd.load()
+wl = bench.WORKLOADS["b64_10s_bf16"]
+cfg = pkg.synth.SynthConfig.full()
+path = bench.checkpoint_path(pkg, wl["file"], 0, lambda: None)
+model = pkg.Model.open(path, device=0, weights=wl["weights"], kv=wl["kv"], max_batch=64)
+voice = model.upload_voice(pkg.VoiceModelState(bench.voice_modules(pkg, cfg)))
+prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
+FRAMES, PER_CLIENT = 125, 3
+window_us = int(os.environ.get("PTTS_WINDOW_US", "3000"))
+for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
+    disp = pkg.Dispatcher([model], max_batch=64, window_us=window_us)
+    lat = []
+    lock = threading.Lock()
+
+    def client(i):
+        c = pkg.RuntimeGenerateConfig(max_steps=FRAMES, eos_threshold=float("inf"), frames_after_eos=3, device_voice=voice, pcm16=True)
+        for k in range(PER_CLIENT):
+            t0 = time.perf_counter()
+            r = disp.generate(prompts[(i * PER_CLIENT + k) % len(prompts)], c)
+            dt = time.perf_counter() - t0
+            assert r.n_frames == FRAMES
+            with lock:
+                lat.append(dt)
+
+    # one warm-up round, then the timed rounds
+    ts = [threading.Thread(target=client, args=(i,)) for i in range(clients)]
+    t0 = time.perf_counter()
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    wall = time.perf_counter() - t0
+    st = disp.stats()
+    audio = clients * PER_CLIENT * FRAMES * bench.FRAME_SEC
+    lat.sort()
+    print(f"clients {clients:4d}  window {window_us} us  {audio/wall:8.1f} x real time  latency p50 {1e3*statistics.median(lat):7.1f} ms  "
+          f"p95 {1e3*lat[int(0.95*(len(lat)-1))]:7.1f} ms  batches {st['batches']:3d}  mean batch {st['mean_batch']:5.1f}  "
+          f"mean queue wait {st['mean_wait_us']/1e3:6.1f} ms", flush=True)
+    disp.close()
+voice.close()
+model.close()
