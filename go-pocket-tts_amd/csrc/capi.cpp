@@ -185,6 +185,55 @@ void ptts_free_result(ptts_result* r) {
     r->n_frames = 0;
 }
 
+struct ptts_chunks { std::vector<TextChunk> v; };
+
+int32_t ptts_text_estimate_max_frames(int64_t token_count, double frame_rate) { return text_estimate_max_frames(token_count, frame_rate); }
+int32_t ptts_text_frames_after_eos(int64_t num_words) { return text_frames_after_eos(num_words); }
+
+int ptts_text_prepare(const char* utf8, int64_t len, char* out, int64_t cap, int64_t* out_len) {
+    return guard([&] {
+        if ((!utf8 && len > 0) || len < 0 || !out_len) throw Error(PTTS_EINVAL, "text: nil argument");
+        const std::string r = text_prepare(std::string(utf8 ? utf8 : "", (size_t)len));
+        *out_len = (int64_t)r.size();
+        if (out && cap > 0) memcpy(out, r.data(), (size_t)std::min<int64_t>(cap, (int64_t)r.size()));
+    });
+}
+
+int ptts_text_chunks(const char* utf8, int64_t len, ptts_encode_fn encode, void* user, int32_t max_tokens, double frame_rate, ptts_chunks** out) {
+    return guard([&] {
+        if ((!utf8 && len > 0) || len < 0 || !encode || !out) throw Error(PTTS_EINVAL, "text: nil argument");
+        TextEncodeFn enc = [&](const std::string& t) {
+            std::vector<int64_t> ids(64);
+            int64_t n = encode(user, t.data(), (int64_t)t.size(), ids.data(), (int64_t)ids.size());
+            if (n > (int64_t)ids.size()) {
+                ids.resize((size_t)n);
+                n = encode(user, t.data(), (int64_t)t.size(), ids.data(), (int64_t)ids.size());
+            }
+            if (n < 0) throw Error(PTTS_EINVAL, "encode \"" + t + "\": tokenizer error");
+            ids.resize((size_t)n);
+            return ids;
+        };
+        std::unique_ptr<ptts_chunks> c(new ptts_chunks());
+        c->v = text_chunks(std::string(utf8 ? utf8 : "", (size_t)len), enc, max_tokens, frame_rate);
+        *out = c.release();
+    });
+}
+
+int32_t ptts_chunks_count(const ptts_chunks* c) { return c ? (int32_t)c->v.size() : 0; }
+
+int ptts_chunks_get(const ptts_chunks* c, int32_t i, ptts_chunk_info* out) {
+    return guard([&] {
+        if (!c || !out || i < 0 || i >= (int32_t)c->v.size()) throw Error(PTTS_EINVAL, "text: chunk index out of range");
+        const TextChunk& t = c->v[(size_t)i];
+        std::memset(out, 0, sizeof *out);
+        out->text = t.text.data(); out->text_len = (int64_t)t.text.size();
+        out->token_ids = t.token_ids.data(); out->n_tokens = (int64_t)t.token_ids.size();
+        out->num_words = t.num_words; out->max_frames = t.max_frames; out->frames_after_eos = t.frames_after_eos;
+    });
+}
+
+void ptts_chunks_free(ptts_chunks* c) { delete c; }
+
 struct ptts_dispatcher { Dispatcher* d; };
 
 int ptts_dispatcher_create(ptts_model* const* models, int32_t n_models, const ptts_dispatch_opts* o, ptts_dispatcher** out) {

@@ -2,6 +2,8 @@
 // prefill, AR step (hipGraph), Mimi decode, GenerateAudio loop.
 #pragma once
 
+#include <functional>
+
 #include "kernels.h"
 #include "model.h"
 
@@ -138,6 +140,20 @@ void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
 std::string request_error(const Desc& d, const ptts_request& q);   // empty: the request is well formed
 
+
+// text front end (text.cpp; internal/text/prepare.go, chunk.go)
+struct TextChunk {
+    std::string text;
+    std::vector<int64_t> token_ids;
+    int num_words = 0, max_frames = 0, frames_after_eos = 0;
+};
+typedef std::function<std::vector<int64_t>(const std::string&)> TextEncodeFn;
+int text_count_words(const std::string& s);
+int text_estimate_max_frames(int64_t token_count, double frame_rate);
+int text_frames_after_eos(int64_t num_words);
+std::string text_prepare(const std::string& input);
+std::vector<std::string> text_split_sentences(const std::string& text);
+std::vector<TextChunk> text_chunks(const std::string& input, const TextEncodeFn& encode, int max_tokens, double frame_rate);
 
 // request dispatcher (dispatcher.cpp)
 struct Dispatcher;

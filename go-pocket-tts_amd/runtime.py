@@ -84,6 +84,8 @@ ABI_SYMBOLS = [
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
+    "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
+    "ptts_chunks_get", "ptts_chunks_free",
 ]
 
 
@@ -703,3 +705,79 @@ class Dispatcher:
         if sys is None or sys.is_finalizing():
             return
         self.close()
+
+
+# ---- text front end (internal/text/prepare.go) ---------------------------------------------------------
+class _ChunkInfo(C.Structure):
+    _fields_ = [("text", C.c_void_p), ("text_len", C.c_int64), ("token_ids", _IP), ("n_tokens", C.c_int64), ("num_words", C.c_int32),
+                ("max_frames", C.c_int32), ("frames_after_eos", C.c_int32), ("reserved", C.c_int32)]
+
+
+_ENCODE_FN = C.CFUNCTYPE(C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, _IP, C.c_int64)
+
+
+@dataclass
+class ChunkMetadata:
+    """text.ChunkMetadata (prepare.go:18-24) + MaxFrames / FramesAfterEOS."""
+    text: str
+    token_ids: list
+    num_words: int
+    max_frames: int
+    frames_after_eos: int
+
+    @property
+    def num_tokens(self) -> int:
+        return len(self.token_ids)
+
+
+def estimate_max_frames(token_count: int, frame_rate: float = 12.5) -> int:
+    L = lib()
+    L.ptts_text_estimate_max_frames.argtypes = [C.c_int64, C.c_double]
+    return int(L.ptts_text_estimate_max_frames(token_count, frame_rate))
+
+
+def frames_after_eos(num_words: int) -> int:
+    L = lib()
+    L.ptts_text_frames_after_eos.argtypes = [C.c_int64]
+    return int(L.ptts_text_frames_after_eos(num_words))
+
+
+def prepare_text(text: str) -> str:
+    """text.PrepareText (prepare.go:66-100)."""
+    L = lib()
+    L.ptts_text_prepare.argtypes = [C.c_char_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+    raw = text.encode("utf-8", "surrogatepass")
+    n = C.c_int64(0)
+    buf = C.create_string_buffer(len(raw) + 16)
+    _check(L.ptts_text_prepare(raw, len(raw), buf, len(buf), C.byref(n)))
+    return buf.raw[: n.value].decode("utf-8", "replace")
+
+
+def prepare_chunks(text: str, encode: Callable[[str], Sequence[int]], max_tokens: int = 50, frame_rate: float = 12.5) -> list:
+    """text.PrepareChunks (prepare.go:105-184); `encode` plays the Tokenizer interface (prepare.go:12-16)."""
+    L = lib()
+    L.ptts_text_chunks.argtypes = [C.c_char_p, C.c_int64, _ENCODE_FN, C.c_void_p, C.c_int32, C.c_double, C.POINTER(C.c_void_p)]
+    L.ptts_chunks_count.argtypes = [C.c_void_p]
+    L.ptts_chunks_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(_ChunkInfo)]
+    L.ptts_chunks_free.argtypes = [C.c_void_p]
+
+    def cb(_user, ptr, n, ids, cap):
+        got = list(encode(C.string_at(ptr, n).decode("utf-8", "replace")))
+        for i, v in enumerate(got[:cap]):
+            ids[i] = int(v)
+        return len(got)
+
+    fn = _ENCODE_FN(cb)
+    raw = text.encode("utf-8", "surrogatepass")
+    h = C.c_void_p()
+    _check(L.ptts_text_chunks(raw, len(raw), fn, None, max_tokens, frame_rate, C.byref(h)))
+    try:
+        out = []
+        for i in range(L.ptts_chunks_count(h)):
+            ci = _ChunkInfo()
+            _check(L.ptts_chunks_get(h, i, C.byref(ci)))
+            out.append(ChunkMetadata(C.string_at(ci.text, ci.text_len).decode("utf-8", "replace"), [int(ci.token_ids[k]) for k in range(ci.n_tokens)],
+                                     int(ci.num_words), int(ci.max_frames), int(ci.frames_after_eos)))
+        return out
+    finally:
+        L.ptts_chunks_free(h)

@@ -143,6 +143,30 @@ void ptts_free_result(ptts_result* r);
  * 24 kHz, mono, 16 bit, RIFF and data sizes 0xFFFFFFFF. */
 void ptts_wav_header_streaming(uint8_t out[44]);
 
+/* ---- Text front end (internal/text/prepare.go, chunk.go) -------------------------------------------------
+ * What Synthesize does before it calls the runtime: normalise the text, cut it into sentence-based chunks of <= max_tokens
+ * tokens, and derive each chunk's step budget and EOS tail.  The SentencePiece encoder is the caller's. */
+int32_t ptts_text_estimate_max_frames(int64_t token_count, double frame_rate);   /* EstimateMaxFrames, prepare.go:38-48 */
+int32_t ptts_text_frames_after_eos(int64_t num_words);                            /* FramesAfterEOS, prepare.go:53-59 */
+/* PrepareText (prepare.go:66-100).  Writes up to cap bytes (no terminator) and the full length to *out_len. */
+int  ptts_text_prepare(const char* utf8, int64_t len, char* out, int64_t cap, int64_t* out_len);
+/* Encoder callback: writes up to cap ids and returns the count (> cap: called again with room), < 0: error. */
+typedef int64_t (*ptts_encode_fn)(void* user, const char* utf8, int64_t len, int64_t* ids, int64_t cap);
+typedef struct ptts_chunks ptts_chunks;
+typedef struct ptts_chunk_info {
+    const char* text; int64_t text_len;            /* PrepareText of the joined sentences */
+    const int64_t* token_ids; int64_t n_tokens;
+    int32_t num_words;                             /* of the raw sentences (prepare.go:140) */
+    int32_t max_frames;                            /* EstimateMaxFrames(n_tokens, frame_rate) */
+    int32_t frames_after_eos;
+    int32_t reserved;
+} ptts_chunk_info;
+/* PrepareChunks (prepare.go:105-184); max_tokens: 50 in the reference's service; frame_rate <= 0: 12.5 */
+int  ptts_text_chunks(const char* utf8, int64_t len, ptts_encode_fn encode, void* user, int32_t max_tokens, double frame_rate, ptts_chunks** out);
+int32_t ptts_chunks_count(const ptts_chunks* c);
+int  ptts_chunks_get(const ptts_chunks* c, int32_t i, ptts_chunk_info* out);
+void ptts_chunks_free(ptts_chunks* c);
+
 /* ---- Request dispatcher (what the reference's worker pool becomes) ----------------------------------
  * internal/server/server.go:132-134,398-421 admits `workers` concurrent Synthesize calls through a semaphore; here callers
  * block in ptts_dispatch_generate and a worker thread per model coalesces waiting requests (up to max_batch, for at most

@@ -34,7 +34,8 @@ def prepare_text(inp: str) -> str:
         s = s.replace("  ", " ")
     s = s.strip()
     if s:
-        s = s[0].upper() + s[1:]
+        up = s[0].upper()   # unicode.ToUpper is the SIMPLE case mapping (one rune): 'ß' has none, str.upper() would give 'SS'
+        s = (up if len(up) == 1 else s[0]) + s[1:]
     if s:
         last = s[-1]
         if last.isalpha() or last.isdigit():
