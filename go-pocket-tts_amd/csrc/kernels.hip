@@ -145,6 +145,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
 void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return;
     static const int force = [] { const char* e = getenv("PTTS_GEMM"); return e ? atoi(e) : 0; }();   // A/B measurement only
+    // a few rows (prefill of a short prompt, batch-1 serving): the step's weight-streaming kernel beats a tile GEMM that would
+    // fill a handful of CUs
+    if (a.M <= 64 && a.Wt && skinny_supported(a, 1)) { launch_skinny(a, SkinnyFuse{}, 1, nullptr, stream); return; }
     if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;
