@@ -468,3 +468,31 @@ def test_dispatcher_coalesces_concurrent_callers_and_returns_each_its_own_audio(
     with pytest.raises(pkg.PttsError, match="token slice must not be empty"):
         d.generate([], cfg(0))
     d.close()
+
+
+def test_mixed_voices_in_one_batch_read_the_right_prefix(pkg, tiny):
+    """The step attention reads a device voice's keys from the voice's own copy (shared by the slots that use it).  One
+    batch with two different device voices (different lengths), a host-supplied voice state and no voice at all must give
+    every request what it gets alone, against the oracle."""
+    cfg, _, om, gm = tiny
+    mods_a = _modules(pkg.synth.make_voice_state(cfg, offset=9, seed=3))
+    mods_b = _modules(pkg.synth.make_voice_state(cfg, offset=5, capacity=8, seed=4))
+    mods_c = _modules(pkg.synth.make_voice_state(cfg, offset=7, seed=5))
+    va, vb = gm.upload_voice(pkg.VoiceModelState(mods_a)), gm.upload_voice(pkg.VoiceModelState(mods_b))
+    toks = [[11, 12], [13, 14, 15], [16], [17, 18], [19, 20, 21]]
+    voices = [("dev", va, mods_a), ("dev", vb, mods_b), ("dev", va, mods_a), ("host", None, mods_c), ("none", None, None)]
+    cfgs = []
+    for kind, dv, mods in voices:
+        kw = dict(eos_threshold=float("inf"), max_steps=3, want_latents=True)
+        if kind == "dev":
+            kw["device_voice"] = dv
+        elif kind == "host":
+            kw["voice_model_state"] = pkg.VoiceModelState(mods)
+        cfgs.append(pkg.RuntimeGenerateConfig(**kw))
+    got = gm.generate_batch(toks, cfgs)
+    for i, (kind, _, mods) in enumerate(voices):
+        ref = om.generate(toks[i], max_steps=3, eos_threshold=1e30, frames_after_eos=3, voice_state=mods)
+        assert got[i].n_frames == 3
+        parity(f"latents[{i}] ({kind})", got[i].latents, ref["latents"], (2e-3, 5e-2))
+        parity(f"pcm[{i}] ({kind})", got[i].pcm, ref["pcm"], (5e-3, 2e-1))
+    va.close(); vb.close()
