@@ -71,6 +71,7 @@ bool skinny_supported(const GemmArgs& a, int splitk);
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
 void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream);
 extern unsigned long long* g_skinny_stamps;
+extern hipEvent_t g_skinny_ev[2];   // when set, launch_skinny times the dispatch with them (hipExtLaunchKernel)
 
 struct LnArgs {
     const float* x = nullptr; RowMap xmap;

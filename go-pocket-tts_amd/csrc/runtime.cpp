@@ -350,12 +350,14 @@ static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = Skinny
     Prof& p = m.prof;
     if (p.on) {
         while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
-        PTTS_HIP(hipEventRecord(p.ev[p.used], st));
+        if (sk) { g_skinny_ev[0] = p.ev[p.used]; g_skinny_ev[1] = p.ev[p.used + 1]; }   // the dispatch stamps itself
+        else PTTS_HIP(hipEventRecord(p.ev[p.used], st));
     }
     if (sk) launch_skinny(g, fu, splitk, partial, st);
     else launch_gemm(g, st);
+    g_skinny_ev[0] = g_skinny_ev[1] = nullptr;
     if (p.on) {
-        PTTS_HIP(hipEventRecord(p.ev[p.used + 1], st));
+        if (!sk) PTTS_HIP(hipEventRecord(p.ev[p.used + 1], st));
         p.used += 2;
         p.launches++;
         p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 * (1 + fu.psplit) + (double)g.M * g.N * 4 * (splitk > 1 ? splitk : 1);
