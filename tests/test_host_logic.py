@@ -97,3 +97,17 @@ def test_synthetic_checkpoint_roundtrips_through_both_readers(pkg, tmp_path):
         assert set(got) == set(want)
         for k in want:
             assert np.array_equal(got[k], want[k].astype(np.float32)), k
+
+
+def test_header_is_plain_c99(tmp_path):
+    """The drop-in boundary is a C ABI: include/ptts.h must compile as C (cgo compiles it as C), warnings as errors."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    src = tmp_path / "t.c"
+    src.write_text('#include "ptts.h"\nint main(void) { ptts_request r; ptts_result s; ptts_dispatch_opts d; ptts_chunk_info c; (void)r; (void)s; (void)d; (void)c;'
+                   ' return sizeof(ptts_result) == 56 && sizeof(ptts_opts) == 64 ? 0 : 1; }\n')
+    exe = tmp_path / "t"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert subprocess.call([str(exe)]) == 0
