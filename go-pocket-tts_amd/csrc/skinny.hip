@@ -132,9 +132,11 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     // Loads are unconditional with clamped indices (a row >= M replays row 0, a column >= klen replays column 0) and the
     // value is masked afterwards; the prologue variant is a template parameter so that a launch only holds the vectors
     // it uses (16 waves per CU leave 128 VGPRs per lane).
-    {
+    // A wave whose row does not exist (batch not a multiple of 16: batch 1 has 15 of them) skips the prologue altogether: its
+    // LDS row feeds only output rows that are never stored, and the SIMD it shares is left to the waves with real rows.
+    if (m0 + wave < p_m) {
         const int m = m0 + wave;
-        const bool m_ok = m < p_m;
+        const bool m_ok = true;
         const int64_t mrow = m_ok ? m : 0;
         float4 xr[NJ];
         int kc[NJ];
