@@ -273,6 +273,8 @@ void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64
 // FlowLM.PromptText -> flowTransformer.prefill (flow_lm.go:155-187, flow_transformer.go:749-771), all slots at once,
 // ragged prompts packed as rows.  The hidden output is discarded by the reference, so the last layer stops after
 // its keys/values are in the cache.
+static int pick_split(int M, int N, int K);
+
 void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
     Model& m = *b.m;
     const Desc& d = m.d;
@@ -309,9 +311,19 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
     float* pff = pattn + (size_t)R * D;
     PTTS_HIP(hipMemcpyAsync(px, rows_dev, (size_t)R * D * f, hipMemcpyDeviceToDevice, s));
     const bool kvb = m.opts.kv == PTTS_KV_BF16;
+    // a short prompt at a small batch (R <= 64 rows): linear2 (K = 4 x d_model) runs as the step's split-K kernel and its
+    // partial sums are added by the next layer's LayerNorm launch, like in the AR step; otherwise it is one tile GEMM
+    const float* pend_partial = nullptr;
+    const float* pend_bias = nullptr;
+    int pend_split = 0;
     for (int l = 0; l < d.n_layers; l++) {
         const auto& L = d.layers[l];
-        launch_layernorm(mkln(m, px, flat(D), L.n1, pxn, D, R), s);
+        {
+            LnArgs ln = mkln(m, px, flat(D), L.n1, pxn, D, R);
+            ln.partial = pend_partial; ln.splitk = pend_split; ln.pstride = (int64_t)R * D; ln.pbias = pend_bias;
+            launch_layernorm(ln, s);
+            pend_partial = nullptr; pend_split = 0;
+        }
         launch_gemm(mk(m, pxn, flat(D), L.in_proj, pqkv, flat(3 * D), R), s);
         launch_rope_rows(pqkv, flat(3 * D), 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
         launch_rope_rows(pqkv, flat(3 * D), D, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
@@ -334,8 +346,15 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
         g1.epi = EPI_GELU;
         launch_gemm(g1, s);
         GemmArgs g2 = mk(m, pff, flat(d.ffn), L.l2, px, flat(D), R);
-        g2.R = px; g2.epi = EPI_RESADD;
-        launch_gemm(g2, s);
+        const int S = R <= 64 ? pick_split((int)R, D, d.ffn) : 1;
+        if (S > 1 && skinny_supported(g2, S)) {
+            DevBuf& pb = m.work(9, (size_t)S * R * D * f);
+            launch_skinny(g2, SkinnyFuse{}, S, pb.as<float>(), s);
+            pend_partial = pb.as<float>(); pend_split = S; pend_bias = m.at<float>(L.l2.b);
+        } else {
+            g2.R = px; g2.epi = EPI_RESADD;
+            launch_gemm(g2, s);
+        }
     }
     for (int sl = 0; sl < B; sl++) b.kv_len_host[sl] += (int32_t)(row_offsets[sl + 1] - row_offsets[sl]);
     h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)B * sizeof(int32_t), s);

@@ -397,6 +397,7 @@ static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float*
         case PRO_LN | PRO_AFFINE | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN: launch_pro<WBF16, PRO_LN>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_PARTIAL: launch_pro<WBF16, PRO_PARTIAL>(a, fu, splitk, partial, grid, stream); break;   // split-K sum + residual, no norm
         default: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_MOD | PRO_PARTIAL>(a, fu, splitk, partial, grid, stream); break;
     }
 }

@@ -496,3 +496,26 @@ def test_mixed_voices_in_one_batch_read_the_right_prefix(pkg, tiny):
         parity(f"latents[{i}] ({kind})", got[i].latents, ref["latents"], (2e-3, 5e-2))
         parity(f"pcm[{i}] ({kind})", got[i].pcm, ref["pcm"], (5e-3, 2e-1))
     va.close(); vb.close()
+
+
+@pytest.mark.parametrize("weights", ["F32", "BF16"])
+def test_split_k_linear2_in_step_and_prefill(pkg, tmp_path, weights):
+    """ffn = 2048 > 1024: linear2 runs split over K (two slices) both in the AR step and in the prefill of a short prompt, and
+    the partial sums are added by the next LayerNorm / fused prologue (the reference checkpoint's ffn = 4096 takes this
+    path; the tiny fixture's 512 does not)."""
+    import dataclasses
+    synth = pkg.synth
+    cfg = dataclasses.replace(synth.SynthConfig.tiny(), ffn=2048)
+    path = str(tmp_path / f"ffn2048_{weights}.safetensors")
+    synth.write_safetensors(path, synth.make_checkpoint(cfg, seed=99), dtype=weights)
+    om = O.OracleModel.from_file(path)
+    gm = pkg.Model.open(path, device=0, weights=1 if weights == "BF16" else 0)
+    toks = [np.array([10, 20, 30, 31, 32], np.int64), np.array([7, 8], np.int64)]
+    got = gm.generate_batch(toks, [pkg.RuntimeGenerateConfig(max_steps=4, eos_threshold=1e30, want_latents=True) for _ in toks])
+    for i, t in enumerate(toks):
+        ref = om.generate(t, max_steps=4, eos_threshold=1e30, frames_after_eos=3)
+        assert got[i].n_frames == 4
+        parity(f"latents[{i}]", got[i].latents, ref["latents"], (2e-3, 5e-2))
+        parity(f"pcm[{i}]", got[i].pcm, ref["pcm"], (5e-3, 2e-1))
+    gm.close()
+    om.close()
