@@ -38,7 +38,7 @@ union Frag3 {
     uint4 q;
 };
 
-int g_gemm3_cfg = 0;   // debug knob (ptts_debug_gemm): 0 = default shape
+thread_local int g_gemm3_cfg = 0;   // debug knob (ptts_debug_gemm): 0 = default shape
 
 template <int BN, bool WBF16, int NW, int CH>
 __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {

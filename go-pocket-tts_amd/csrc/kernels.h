@@ -51,7 +51,7 @@ bool gemm2_supported(const GemmArgs& a);
 void launch_gemm2(const GemmArgs& a, hipStream_t stream);
 bool gemm3_supported(const GemmArgs& a);   // direct-to-register activations, 256-row blocks (gemm3.hip)
 void launch_gemm3(const GemmArgs& a, hipStream_t stream);
-extern int g_gemm3_cfg;
+extern thread_local int g_gemm3_cfg;
 
 // Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.
@@ -70,8 +70,8 @@ struct SkinnyFuse {
 bool skinny_supported(const GemmArgs& a, int splitk);
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
 void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream);
-extern unsigned long long* g_skinny_stamps;
-extern hipEvent_t g_skinny_ev[2];   // when set, launch_skinny times the dispatch with them (hipExtLaunchKernel)
+extern thread_local unsigned long long* g_skinny_stamps;
+extern thread_local hipEvent_t g_skinny_ev[2];   // when set, launch_skinny times the dispatch with them (hipExtLaunchKernel)
 
 struct LnArgs {
     const float* x = nullptr; RowMap xmap;

@@ -359,8 +359,8 @@ bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
            !f.pgate && (!f.ln_w == !f.ln_b) && (!f.partial || f.psplit >= 1) && (f.ln || !(f.ln_w || f.scale));
 }
 
-hipEvent_t g_skinny_ev[2] = {nullptr, nullptr};   // measurement pass (bench.py roofline): the kernel's own begin / end timestamps
-unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_stamps)
+thread_local hipEvent_t g_skinny_ev[2] = {nullptr, nullptr};   // measurement pass (bench.py roofline): the kernel's own begin / end timestamps
+thread_local unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_stamps)
 
 template <bool WBF16, int PRO, int NJ, int CG>
 static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
