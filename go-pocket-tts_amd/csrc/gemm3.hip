@@ -179,6 +179,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
                 const float4 b = *reinterpret_cast<const float4*>(a.bias + col);
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             }
+            if (a.rope_cos && col < a.rope_cols) {   // the lane's four columns are two (even, odd) pairs of one head
+                const int pos = a.rope_pos0 + (a.rope_rows_per_seg ? m % a.rope_rows_per_seg : m);
+                const int half = a.rope_hd >> 1, j = (col % a.rope_hd) >> 1;
+                const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (int64_t)pos * half + j);
+                const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (int64_t)pos * half + j);
+                const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
+                v.x = x0 * cs.x - x1 * sn.x; v.y = x0 * sn.x + x1 * cs.x;
+                v.z = x2 * cs.y - x3 * sn.y; v.w = x2 * sn.y + x3 * cs.y;
+            }
             const int64_t co = ro + col;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.epi >= EPI_RESADD) r = *reinterpret_cast<const float4*>(a.R + co);
@@ -218,7 +227,8 @@ bool gemm3_supported(const GemmArgs& a) {
     return a.M >= 512 && a.K % 32 == 0 && a.N % 4 == 0 && aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0 &&
            a.ldw % kalign == 0 && aligned16(a.W) && aligned16(a.C) && a.cmap.ld % 4 == 0 && a.cmap.batch_stride % 4 == 0 &&
            (!a.bias || aligned16(a.bias)) && (!a.addvec || aligned16(a.addvec)) && (!a.scale || aligned16(a.scale)) &&
-           (!res || aligned16(a.R)) && (a.epi != EPI_GATE_RESADD || (aligned16(a.gate) && a.ldg % 4 == 0));
+           (!res || aligned16(a.R)) && (a.epi != EPI_GATE_RESADD || (aligned16(a.gate) && a.ldg % 4 == 0)) &&
+           (!a.rope_cos || (a.rope_hd % 4 == 0 && a.rope_cols % 4 == 0 && a.epi == EPI_NONE));
 }
 
 template <int BN, int NW, int CH>

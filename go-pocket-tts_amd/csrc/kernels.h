@@ -42,6 +42,9 @@ struct GemmArgs {
     const float* scale = nullptr;    // [N]
     const float* gate = nullptr; int64_t ldg = 0;
     float alpha = 1.0f;
+    // k_gemm3 only: interleaved-pair RoPE (rope.go:81-105) applied to the first rope_cols output columns before they are
+    // stored (q and k of a qkv projection); row m sits at position rope_pos0 + m % rope_rows_per_seg (0: m)
+    const float* rope_cos = nullptr; const float* rope_sin = nullptr; int rope_cols = 0, rope_hd = 64, rope_pos0 = 0, rope_rows_per_seg = 0;
     float* tail = nullptr;           // k_skinny only: the LAST column goes, as acc + bias without the epilogue, to tail[m] instead of C
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;

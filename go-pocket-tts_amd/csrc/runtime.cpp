@@ -667,9 +667,18 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         float* qkvx = qkv + (size_t)t0 * 3 * C;
         const RowMap qm = seg(3 * C, CT, (int64_t)T1 * 3 * C);
         launch_layernorm(mkln(m, upx, upm, L.n1, n1, C, R), s);
-        launch_gemm(mk(m, n1, flat(C), L.in_proj, qkvx, qm, R), s);
-        launch_rope_rows(qkvx, qm, 0, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
-        launch_rope_rows(qkvx, qm, C, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        {
+            GemmArgs gq = mk(m, n1, flat(C), L.in_proj, qkvx, qm, R);
+            gq.rope_cos = m.at<float>(d.rope_cos); gq.rope_sin = m.at<float>(d.rope_sin);   // q and k are rotated in the epilogue
+            gq.rope_cols = 2 * C; gq.rope_hd = d.mimi_hd; gq.rope_pos0 = t0; gq.rope_rows_per_seg = CT;
+            if (gemm3_supported(gq)) launch_gemm3(gq, s);
+            else {
+                gq.rope_cos = gq.rope_sin = nullptr;
+                launch_gemm(gq, s);
+                launch_rope_rows(qkvx, qm, 0, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+                launch_rope_rows(qkvx, qm, C, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+            }
+        }
         AttnArgs a;
         a.q = qkvx; a.q_ld = 3 * C; a.q_col0 = 0; a.q_rows_per_batch = CT; a.q_batch_stride = (int64_t)T1 * 3 * C;
         a.k = qkv + C; a.v = qkv + 2 * C; a.kv_bf16 = 0;

@@ -519,3 +519,14 @@ def test_split_k_linear2_in_step_and_prefill(pkg, tmp_path, weights):
         parity(f"pcm[{i}]", got[i].pcm, ref["pcm"], (5e-3, 2e-1))
     gm.close()
     om.close()
+
+
+def test_mimi_decode_many_rows_takes_the_big_gemm_path(tiny):
+    """2 x 20 frames = 640 decoder-transformer rows (>= 512): the direct-to-register GEMM with RoPE in its epilogue, the
+    window attention across two utterances of a batch and the range decode all at once, against the oracle."""
+    _, _, om, gm = tiny
+    rng = np.random.default_rng(12)
+    lat = (rng.standard_normal((2, 20, 32)) * 0.5).astype(np.float32)
+    pcm = gm.decode_latents(lat)
+    for b in range(2):
+        parity(f"mimi_decode 20 frames [{b}]", pcm[b], om.mimi_decode(om.latent_to_mimi(lat[b])), DECONV_TOL)
