@@ -167,6 +167,8 @@ void launch_conv_final(const float* in, int in_pad_rows, const float* w /*[k*C]*
 void launch_zero_rows(float* base, int64_t batch_stride, int b, int64_t n, hipStream_t stream);
 // PCM egress: out[i] = int16(clamp(in[i], -1, 1) * 32767), product in f64, truncation, NaN -> 0 (audio/wav_stream.go:43-54); n % 8 == 0 or any n
 void launch_pcm16(const float* in, int16_t* out, int64_t n, hipStream_t stream);
+// the same on samples [off, off + n) of each of `rows` rows (row_stride samples apart; off, n, row_stride % 8 == 0)
+void launch_pcm16_rows(const float* in, int16_t* out, int rows, int64_t row_stride, int64_t off, int64_t n, hipStream_t stream);
 
 // One SEANet residual block (+ optionally the final conv) as a single launch, resblock.hip.  u / uo: channels-last
 // [B][pad + L][C] with `pad` zero history rows per utterance; rows [t0, t1) of every utterance are produced.

@@ -633,6 +633,17 @@ __global__ void k_pcm16(const float* in, int16_t* out, int64_t n) {
         for (int64_t j = i; j < n; j++) out[j] = (int16_t)pcm16_one(in[j]);
     }
 }
+__global__ void k_pcm16_rows(const float* in, int16_t* out, int64_t row_stride, int64_t off, int64_t n) {
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    const int64_t base = (int64_t)blockIdx.y * row_stride + off + i;
+    for (int j = 0; j < 8 && i + j < n; j++) out[base + j] = (int16_t)pcm16_one(in[base + j]);
+}
+void launch_pcm16_rows(const float* in, int16_t* out, int rows, int64_t row_stride, int64_t off, int64_t n, hipStream_t stream) {
+    if (n <= 0 || rows <= 0) return;
+    const int64_t threads = (n + 7) / 8;
+    hipLaunchKernelGGL(k_pcm16_rows, dim3((unsigned)((threads + 255) / 256), (unsigned)rows), dim3(256), 0, stream, in, out, row_stride, off, n);
+}
 void launch_pcm16(const float* in, int16_t* out, int64_t n, hipStream_t stream) {
     if (n <= 0) return;
     const int64_t threads = (n + 7) / 8;

@@ -980,9 +980,36 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     mimi_setup(m, mw, B, T);
     DevBuf& pcm = m.work(7, (size_t)B * T * spf * sizeof(float));
     const char* env_chunk = getenv("PTTS_MIMI_CHUNK");
-    const int chunk = env_chunk && atoi(env_chunk) > 0 ? atoi(env_chunk) : 1 << 30;   // default: decode after the loop (measured: overlapping
-                                                                                      // slows the AR launches by as much as it hides)
-    int f_done = 0, steps_run = 0;
+    int chunk = env_chunk && atoi(env_chunk) > 0 ? atoi(env_chunk) : 1 << 30;   // default: decode after the loop (measured: overlapping
+                                                                                // slows the AR launches by as much as it hides)
+    // Streaming (pcm_callback): ranges of `chunk` frames are decoded on stream2 behind the AR loop, copied into the buffers
+    // the results will own and announced from a host function queued on that stream (a HIP runtime thread).
+    struct StreamChunk {
+        const ptts_request* reqs; const int* idx; const char* cancelled; void* const* host; int B;
+        int f0, f1; int64_t spf;
+        int32_t* nf;   // pinned: n_frames of every slot, read after the range's last step
+    };
+    bool streaming = false;
+    for (int i = 0; i < B; i++) streaming |= reqs[idx[i]].pcm_callback != nullptr;
+    std::vector<void*> stream_host((size_t)B, nullptr);
+    std::vector<std::unique_ptr<StreamChunk>> stream_chunks;
+    std::vector<int32_t*> stream_nf;
+    DevBuf* stream_s16 = nullptr;
+    if (streaming) {
+        chunk = 1 << 30;
+        bool any_s16 = false;
+        for (int i = 0; i < B; i++) {
+            const ptts_request& r = reqs[idx[i]];
+            if (!r.pcm_callback) continue;
+            chunk = std::min(chunk, r.stream_frames > 0 ? (int)r.stream_frames : 12);
+            const size_t esz = r.pcm_format == PTTS_PCM_S16 ? sizeof(int16_t) : sizeof(float);
+            stream_host[(size_t)i] = result_alloc((size_t)std::max<int64_t>(1, (int64_t)ms[i] * spf) * esz);
+            if (!stream_host[(size_t)i]) throw Error(PTTS_ENOMEM, "ptts-hip: out of host memory");
+            any_s16 |= r.pcm_format == PTTS_PCM_S16;
+        }
+        if (any_s16) stream_s16 = &m.work(8, (size_t)B * T * spf * sizeof(int16_t));
+    }
+    int f_done = 0, f_emitted = 0, steps_run = 0;
     size_t ev_used = 0;
     auto decode_upto = [&](int f1) {
         if (f1 <= f_done) return;
@@ -992,6 +1019,39 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         PTTS_HIP(hipStreamWaitEvent(m.stream2, e, 0));
         mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2);
         f_done = f1;
+    };
+    auto emit_upto = [&](int f1) {   // hand frames [f_emitted, f1) to the streaming callbacks (they are decoded: f1 <= f_done)
+        if (!streaming || f1 <= f_emitted) return;
+        const int f0 = f_emitted;
+        hipStream_t s2 = m.stream2;
+        if (stream_s16) launch_pcm16_rows(pcm.as<float>(), stream_s16->as<int16_t>(), B, (int64_t)T * spf, (int64_t)f0 * spf, (int64_t)(f1 - f0) * spf, s2);
+        for (int i = 0; i < B; i++) {
+            if (!stream_host[(size_t)i]) continue;
+            const int fe = std::min(f1, ms[i]);
+            if (fe <= f0) continue;
+            const bool s16 = reqs[idx[i]].pcm_format == PTTS_PCM_S16;
+            const size_t esz = s16 ? sizeof(int16_t) : sizeof(float);
+            const char* src = s16 ? (const char*)stream_s16->p : (const char*)pcm.p;
+            PTTS_HIP(hipMemcpyAsync((char*)stream_host[(size_t)i] + (size_t)f0 * spf * esz, src + ((size_t)i * T * spf + (size_t)f0 * spf) * esz,
+                                    (size_t)(fe - f0) * spf * esz, hipMemcpyDeviceToHost, s2));
+        }
+        int32_t* nfp = nullptr;
+        PTTS_HIP(hipHostMalloc((void**)&nfp, (size_t)B * sizeof(int32_t), hipHostMallocDefault));
+        stream_nf.push_back(nfp);
+        PTTS_HIP(hipMemcpyAsync(nfp, b.st.n_frames, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost, s2));
+        stream_chunks.emplace_back(new StreamChunk{reqs, idx.data(), cancelled.data(), stream_host.data(), B, f0, f1, spf, nfp});
+        PTTS_HIP(hipLaunchHostFunc(s2, [](void* p) {
+            const StreamChunk& c = *static_cast<const StreamChunk*>(p);
+            for (int i = 0; i < c.B; i++) {
+                const ptts_request& r = c.reqs[c.idx[i]];
+                if (!r.pcm_callback || !c.host[i] || c.cancelled[i]) continue;
+                const int end = std::min(c.f1, (int)c.nf[i]);   // frames past the utterance's end are not audio
+                if (end <= c.f0) continue;
+                const size_t esz = r.pcm_format == PTTS_PCM_S16 ? sizeof(int16_t) : sizeof(float);
+                r.pcm_callback(r.pcm_user, (int64_t)c.f0 * c.spf, (int64_t)(end - c.f0) * c.spf, (const char*)c.host[i] + (size_t)c.f0 * c.spf * esz);
+            }
+        }, stream_chunks.back().get()));
+        f_emitted = f1;
     };
     for (int step = 0; step < ms_max; step++) {
         int n_cancel = 0;
@@ -1003,7 +1063,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         if (n_cancel == B) break;
         enqueue_step(b, lsd, use_graph);
         steps_run = step + 1;
-        if (steps_run % chunk == 0) decode_upto(steps_run);
+        if (steps_run % chunk == 0) { decode_upto(steps_run); emit_upto(steps_run); }
         if (any_cb) {  // StepCallback runs synchronously after the step (:194-196)
             std::vector<int32_t> before = act, broke((size_t)B);
             d2h(act.data(), b.st.active, (size_t)B * 4, s);
@@ -1029,7 +1089,10 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     for (int i = 0; i < B; i++) if (!cancelled[i]) Tmax = std::max(Tmax, nf[i]);
     if (Tmax > 0) {
         decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
+        emit_upto(std::min(steps_run, Tmax));
         PTTS_HIP(hipStreamSynchronize(m.stream2));
+        for (int32_t* p : stream_nf) (void)hipHostFree(p);
+        stream_nf.clear();
         DevBuf* pcm_s16 = nullptr;   // PCM16 egress on the device (audio/wav_stream.go:43-54) for the requests that ask for it
         {
             bool any_s16 = false;
@@ -1046,7 +1109,11 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             r.n_frames = nf[i];
             r.eos_step = es[i];
             r.n_samples = (int64_t)nf[i] * spf;
-            if (reqs[idx[i]].pcm_format == PTTS_PCM_S16) {
+            if (stream_host[(size_t)i]) {   // streamed: the buffer already holds every sample that was announced
+                if (reqs[idx[i]].pcm_format == PTTS_PCM_S16) r.pcm16 = (int16_t*)stream_host[(size_t)i];
+                else r.pcm = (float*)stream_host[(size_t)i];
+                stream_host[(size_t)i] = nullptr;
+            } else if (reqs[idx[i]].pcm_format == PTTS_PCM_S16) {
                 r.pcm16 = (int16_t*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(int16_t));
                 if (!r.pcm16) { fail_req(r, PTTS_ENOMEM); continue; }
                 if (r.n_samples > 0)
@@ -1068,8 +1135,10 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         mark("results d2h");
     } else {
         PTTS_HIP(hipStreamSynchronize(m.stream2));
+        for (int32_t* p : stream_nf) (void)hipHostFree(p);
         for (int i = 0; i < B; i++) fail_req(res[idx[i]], PTTS_ECANCELLED);
     }
+    for (void* p : stream_host) result_free(p);   // buffers of cancelled / failed streaming requests
 }
 
 std::string request_error(const Desc& d, const ptts_request& q) {   // the argument checks of GenerateAudio (runtime_native_safetensors.go:52-119)

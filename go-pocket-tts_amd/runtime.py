@@ -28,6 +28,7 @@ KV_F32, KV_BF16 = 0, 1
 _FP = C.POINTER(C.c_float)
 _IP = C.POINTER(C.c_int64)
 _STEP_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_int32)
+_PCM_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p)
 
 
 class PttsError(RuntimeError):
@@ -59,7 +60,8 @@ class _Request(C.Structure):
                 ("frames_after_eos", C.c_int32), ("voice_embedding", _FP), ("voice_frames", C.c_int64),
                 ("voice_caches", C.POINTER(_FP)), ("voice_cache_steps", _IP), ("voice_offsets", _IP), ("noise", _FP),
                 ("step_callback", _STEP_CB), ("callback_user", C.c_void_p), ("cancel", C.POINTER(C.c_int32)),
-                ("want_latents", C.c_int32), ("pcm_format", C.c_int32), ("voice", C.c_void_p), ("reserved", C.c_int32 * 4)]
+                ("want_latents", C.c_int32), ("pcm_format", C.c_int32), ("voice", C.c_void_p), ("reserved", C.c_int32 * 4),
+                ("pcm_callback", _PCM_CB), ("pcm_user", C.c_void_p), ("stream_frames", C.c_int32), ("reserved2", C.c_int32 * 3)]
 
 
 class _Profile(C.Structure):
@@ -206,6 +208,10 @@ class RuntimeGenerateConfig:
     cancel: Optional[np.ndarray] = None  # int32[1]; nonzero = cancelled (the ctx of GenerateAudio)
     want_latents: bool = False
     pcm16: bool = False   # PCM egress on the device: GenerateResult.pcm is int16 = audio.WritePCM16Samples (wav_stream.go:43-54)
+    # frame-granular streaming: pcm_callback(sample_offset, samples) is called from a library thread for consecutive ranges of
+    # `stream_frames` frames while generation is still running (samples: a copy, float32 or int16 per pcm16)
+    pcm_callback: Optional[Callable[[int, np.ndarray], None]] = None
+    stream_frames: int = 0
 
 
 class _OwnedBuffer:
@@ -384,6 +390,16 @@ class Model:
             r.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
         r.want_latents = 1 if cfg.want_latents else 0
         r.pcm_format = 1 if getattr(cfg, "pcm16", False) else 0
+        if getattr(cfg, "pcm_callback", None) is not None:
+            dt = np.int16 if r.pcm_format else np.float32
+
+            def _pcm(_u, off, n, ptr, f=cfg.pcm_callback, dt=dt):
+                f(int(off), np.frombuffer(C.string_at(ptr, int(n) * np.dtype(dt).itemsize), dtype=dt))
+
+            pcb = _PCM_CB(_pcm)
+            keep.append(pcb)
+            r.pcm_callback = pcb
+            r.stream_frames = int(getattr(cfg, "stream_frames", 0))
 
     def _take_result(self, rs, cfg) -> "GenerateResult":
         s16 = bool(getattr(cfg, "pcm16", False))   # PCM16 egress: int16 samples encoded on the device

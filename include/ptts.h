@@ -94,6 +94,8 @@ void   ptts_plan_free(ptts_plan* p);
 /* ---- the Runtime seam: tts.Runtime.GenerateAudio (runtime_native_safetensors.go:52-238) ---- */
 typedef void (*ptts_step_callback)(void* user, int32_t step, int32_t max_steps); /* RuntimeGenerateConfig.StepCallback */
 
+typedef void (*ptts_pcm_callback)(void* user, int64_t sample_offset, int64_t n_samples, const void* samples);
+
 #define PTTS_PCM_F32 0
 #define PTTS_PCM_S16 1
 
@@ -122,6 +124,13 @@ typedef struct ptts_request {
      * every chunk (service.go:127,216-246, flow_lm.go:134-145); the device copy is that cached voice. */
     const ptts_voice* voice;
     int32_t reserved[4];
+    /* Frame-granular streaming (the /tts/stream path, server.go:354-396, at finer grain than the reference's per-chunk
+     * PCMChunk): finished frame ranges are decoded while the AR loop is still running and handed over in order, each sample
+     * exactly once, from a library thread; `samples` points into the buffer the result will own (float or int16 per
+     * pcm_format).  The callback must not call into this library.  stream_frames: frames per hand-over (<= 0: 12 = 0.96 s). */
+    ptts_pcm_callback pcm_callback; void* pcm_user;
+    int32_t stream_frames;
+    int32_t reserved2[3];
 } ptts_request;
 
 typedef struct ptts_result {

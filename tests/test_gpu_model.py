@@ -530,3 +530,37 @@ def test_mimi_decode_many_rows_takes_the_big_gemm_path(tiny):
     pcm = gm.decode_latents(lat)
     for b in range(2):
         parity(f"mimi_decode 20 frames [{b}]", pcm[b], om.mimi_decode(om.latent_to_mimi(lat[b])), DECONV_TOL)
+
+
+@pytest.mark.parametrize("pcm16", [False, True])
+def test_streaming_callbacks_deliver_every_sample_once_in_order(pkg, tiny, pcm16):
+    """Frame-granular streaming (the /tts/stream path): ranges of 2 frames are announced while generation runs; per request
+    the ranges are consecutive from 0, stop at that request's own length (ragged batch) and concatenate to exactly the audio
+    the same call returns, which equals the non-streaming audio up to kernel-selection rounding (a 2-frame range is decoded
+    by other GEMM kernels than a whole utterance)."""
+    _, _, om, gm = tiny
+    toks = [np.array([10, 20, 30], np.int64), np.array([5, 6], np.int64), np.array([7, 8, 9, 11], np.int64)]
+    steps = [5, 3, 4]
+    base = [pkg.RuntimeGenerateConfig(max_steps=steps[i], eos_threshold=1e30, pcm16=pcm16) for i in range(3)]
+    want = gm.generate_batch(toks, base)
+    got_chunks = [[] for _ in toks]
+
+    def mk(i):
+        return lambda off, x: got_chunks[i].append((off, x.copy()))
+
+    cfgs = [pkg.RuntimeGenerateConfig(max_steps=steps[i], eos_threshold=1e30, pcm16=pcm16, pcm_callback=(mk(i) if i != 1 else None), stream_frames=2)
+            for i in range(3)]
+    got = gm.generate_batch(toks, cfgs)
+    for i in range(3):
+        assert got[i].n_frames == steps[i]
+        if pcm16:
+            assert np.abs(got[i].pcm.astype(np.int32) - want[i].pcm.astype(np.int32)).max() <= 2
+        else:
+            parity(f"streamed vs whole [{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
+        if i == 1:
+            assert not got_chunks[i]      # no callback: not streamed, same result
+            continue
+        offs = [o for o, _ in got_chunks[i]]
+        assert offs[0] == 0 and all(offs[k + 1] == offs[k] + got_chunks[i][k][1].size for k in range(len(offs) - 1))
+        assert len(got_chunks[i]) == (steps[i] + 1) // 2 and all(c.size % 1920 == 0 for _, c in got_chunks[i])
+        assert np.array_equal(np.concatenate([c for _, c in got_chunks[i]]), got[i].pcm)
