@@ -5,5 +5,5 @@ runtime.py host-side mirror of tts.Runtime / native.Model over that C ABI
 synth.py   synthetic checkpoints / voices / prompts (no real weights exist offline)
 """
 from . import runtime, synth  # noqa: F401
-from .runtime import (Batch, Cancelled, DeviceVoice, Dispatcher, GenerateResult, Model, PttsError, Runtime, RuntimeGenerateConfig,  # noqa: F401
+from .runtime import (Batch, Cancelled, DeviceVoice, Dispatcher, GenerateResult, Model, PttsError, Runtime, RuntimeGenerateConfig, Service, TTSConfig,  # noqa: F401
                       VoiceEmbedding, VoiceModelState, KV_BF16, KV_F32, WEIGHTS_BF16, WEIGHTS_F32)

@@ -797,3 +797,56 @@ def prepare_chunks(text: str, encode: Callable[[str], Sequence[int]], max_tokens
         return out
     finally:
         L.ptts_chunks_free(h)
+
+
+# ---- tts.Service (internal/tts/service.go): text in, audio out --------------------------------------------------------------
+MAX_TOKENS_PER_CHUNK = 50          # service.go:21-23
+DEFAULT_MAX_STEPS = 256            # config.DefaultConfig().TTS.MaxSteps: "use the estimate" (service.go:271-278)
+
+
+@dataclass
+class TTSConfig:
+    """The config.TTS fields generateConfig reads (service.go:255-269)."""
+    temperature: float = 0.0
+    eos_threshold: float = -4.0
+    max_steps: int = DEFAULT_MAX_STEPS
+    lsd_decode_steps: int = 1
+
+
+class Service:
+    """tts.Service: PrepareChunks -> one GenerateAudio per chunk -> concatenated PCM (service.go:107-153).
+
+    The reference generates the chunks one after the other.  They are independent (each chunk starts from the voice
+    state), so here ALL chunks of a text go to the runtime in one batched call (or through a Dispatcher, where they are
+    coalesced with other callers' chunks): a one-minute text costs about what one 10-second chunk costs."""
+
+    def __init__(self, model: Model, encode: Callable[[str], Sequence[int]], tts: Optional[TTSConfig] = None, dispatcher: Optional["Dispatcher"] = None):
+        self.model, self.encode, self.tts, self.dispatcher = model, encode, tts or TTSConfig(), dispatcher
+
+    def generate_config(self, chunk: "ChunkMetadata", **voice) -> RuntimeGenerateConfig:   # service.go:255-278
+        frame_rate, _, spl = self.model.info.frame_rate, self.model.info.encoder_frame_rate, self.model.info.steps_per_latent
+        est = estimate_max_frames(chunk.num_tokens, frame_rate)
+        limit = est if est > 0 and (self.tts.max_steps <= 0 or self.tts.max_steps == DEFAULT_MAX_STEPS) else self.tts.max_steps
+        return RuntimeGenerateConfig(temperature=self.tts.temperature, eos_threshold=self.tts.eos_threshold, max_steps=limit,
+                                     estimated_max_steps=est, lsd_decode_steps=self.tts.lsd_decode_steps, frames_after_eos=chunk.frames_after_eos,
+                                     mimi_steps_per_latent=spl, mimi_sequence_length=est * spl, **voice)
+
+    def synthesize_chunks(self, text: str, **voice) -> list:
+        """[(ChunkMetadata, GenerateResult)] in text order."""
+        try:
+            chunks = prepare_chunks(text, self.encode, MAX_TOKENS_PER_CHUNK, self.model.info.frame_rate)
+        except PttsError as e:
+            raise PttsError(e.code, f"no tokens produced from input: {e}") from None   # service.go:124-126
+        cfgs = [self.generate_config(c, **voice) for c in chunks]
+        if self.dispatcher is not None:
+            import concurrent.futures as cf
+            with cf.ThreadPoolExecutor(max_workers=len(chunks)) as ex:
+                res = list(ex.map(lambda cc: self.dispatcher.generate(cc[0].token_ids, cc[1]), zip(chunks, cfgs)))
+        else:
+            res = self.model.generate_batch([c.token_ids for c in chunks], cfgs)
+        return list(zip(chunks, res))
+
+    def synthesize(self, text: str, **voice) -> np.ndarray:
+        """Service.Synthesize (service.go:107-153): the chunks' PCM, concatenated."""
+        parts = [r.pcm for _, r in self.synthesize_chunks(text, **voice)]
+        return np.concatenate(parts) if parts else np.zeros(0, np.float32)

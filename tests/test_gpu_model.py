@@ -564,3 +564,30 @@ def test_streaming_callbacks_deliver_every_sample_once_in_order(pkg, tiny, pcm16
         assert offs[0] == 0 and all(offs[k + 1] == offs[k] + got_chunks[i][k][1].size for k in range(len(offs) - 1))
         assert len(got_chunks[i]) == (steps[i] + 1) // 2 and all(c.size % 1920 == 0 for _, c in got_chunks[i])
         assert np.array_equal(np.concatenate([c for _, c in got_chunks[i]]), got[i].pcm)
+
+
+def test_service_synthesize_batches_the_chunks_of_a_text(pkg, tiny):
+    """tts.Service.Synthesize (service.go:107-153): PrepareChunks, per-chunk step budget and EOS tail, concatenation.  The
+    chunks run as one batch; the result must equal the reference's order of operations -- one GenerateAudio per chunk, one
+    after the other (here against the oracle) -- with a word-hash tokenizer standing in for SentencePiece."""
+    cfg, _, om, gm = tiny
+    vocab = cfg.n_bins
+
+    def encode(t):
+        return [1 + (sum(ord(ch) * (k + 1) for k, ch in enumerate(w)) % (vocab - 1)) for w in t.split()]
+
+    text = "the quick brown fox jumps over the lazy dog. it was a bright cold day in april! and the clocks were striking thirteen? yes."
+    svc = pkg.Service(gm, encode, pkg.TTSConfig(eos_threshold=float("inf"), max_steps=3))   # fixed 3 steps per chunk keeps the oracle run short
+    pairs = svc.synthesize_chunks(text)
+    chunks = pkg.runtime.prepare_chunks(text, encode, 50)
+    assert [c.text for c, _ in pairs] == [c.text for c in chunks] and len(chunks) >= 1
+    want = []
+    for c in chunks:
+        assert c.max_frames == pkg.runtime.estimate_max_frames(len(c.token_ids)) and c.frames_after_eos in (3, 5)
+        want.append(om.generate(c.token_ids, max_steps=3, eos_threshold=1e30, frames_after_eos=c.frames_after_eos)["pcm"])
+    got = svc.synthesize(text)
+    parity("service pcm", got, np.concatenate(want), (5e-3, 2e-1))
+    # estimate-driven budget: with the default max_steps the limit is EstimateMaxFrames of the chunk
+    assert pkg.Service(gm, encode).generate_config(chunks[0]).max_steps == chunks[0].max_frames
+    with pytest.raises(pkg.PttsError, match="no tokens produced from input"):
+        svc.synthesize("   ")
