@@ -185,7 +185,8 @@ void ptts_chunks_free(ptts_chunks* c);
 typedef struct ptts_dispatcher ptts_dispatcher;
 typedef struct ptts_dispatch_opts {
     int32_t max_batch;    /* <= 0: the model's max_batch */
-    int32_t window_us;    /* coalescing window, counted from the arrival of the oldest waiting request */
+    int32_t window_us;    /* coalescing window, counted from the arrival of the oldest waiting request; stretched (to at most
+                           * 4 windows) while requests keep arriving less than window_us / 4 apart */
     int32_t queue_cap;    /* <= 0: 4096; a full queue answers PTTS_ENOMEM */
     int32_t reserved[5];
 } ptts_dispatch_opts;

@@ -135,3 +135,19 @@ def test_two_workers_drain_one_queue(pkg):
     assert set(seen) == {0, 1}               # both workers took batches ...
     assert dt < 0.15 * 4 * 0.9 + 0.3         # ... concurrently: 4 batches of 2 in about two rounds, not four
     d.close()
+
+
+def test_window_stretches_while_requests_keep_arriving(pkg):
+    """A burst that trickles in (one request every 8 ms, window 50 ms, so window / 4 = 12.5 ms counts as quiet) is not cut at
+    the window: the batch leaves once the arrivals pause, at most four windows after the first request."""
+    batches = []
+    d = pkg.Dispatcher([], max_batch=64, window_us=50_000, _custom_exec=make_exec(batches))
+    t0 = time.perf_counter()
+    run_clients(d, pkg, 12, stagger=0.008)         # arrivals over ~90 ms: past the 50 ms window
+    dt = time.perf_counter() - t0
+    assert batches == [list(range(1, 13))], batches
+    assert dt < 0.2 + 0.1                          # hard stop at 4 windows
+    batches.clear()
+    run_clients(d, pkg, 40, stagger=0.008)         # ~320 ms of arrivals: the 200 ms cap cuts the burst
+    assert len(batches) >= 2 and sum(len(b) for b in batches) == 40
+    d.close()
