@@ -121,6 +121,15 @@ int ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_mod
     return rc;
 }
 
+int ptts_model_share(ptts_model* base, ptts_model** out) {
+    return guard([&] {
+        if (!base || !base->m || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::unique_ptr<ptts_model> h(new ptts_model());
+        h->m = model_share(*base->m);
+        *out = h.release();
+    });
+}
+
 int ptts_model_open(const char* path, const ptts_opts* opts, ptts_model** out) {
     ptts_plan* pl = nullptr;
     int rc = ptts_plan_create(path, opts, &pl);

@@ -25,7 +25,7 @@ using Clock = std::chrono::steady_clock;
 struct DispatchItem {
     const ptts_request* req = nullptr;
     ptts_result* res = nullptr;
-    const Model* pinned = nullptr;      // a device-resident voice ties the request to the model (GPU) that holds it
+    const Voice* voice = nullptr;       // a device-resident voice ties the request to the models that can read it (same GPU)
     Clock::time_point enq;
     int rc = PTTS_OK;
     std::string err;
@@ -63,7 +63,7 @@ void Dispatcher::run(int w) {
         std::vector<DispatchItem*> batch;
         {
             std::unique_lock<std::mutex> lock(mu);
-            auto eligible = [&](const DispatchItem* it) { return !it->pinned || it->pinned == model; };
+            auto eligible = [&](const DispatchItem* it) { return !it->voice || !model || voice_usable_by(*it->voice, *model); };
             auto first = [&]() -> DispatchItem* {
                 for (DispatchItem* it : queue) if (eligible(it)) return it;
                 return nullptr;
@@ -191,9 +191,9 @@ int dispatcher_generate(Dispatcher* d, const ptts_request* req, ptts_result* res
         std::string e = request_error(d->models[0]->d, *req);   // refuse malformed requests before they cost a batch slot
         if (!e.empty()) { *err = e; res->status = PTTS_EINVAL; return PTTS_EINVAL; }
         if (req->voice) {
-            item.pinned = reinterpret_cast<const Voice*>(req->voice)->m;
+            item.voice = reinterpret_cast<const Voice*>(req->voice);
             bool served = false;
-            for (Model* m : d->models) served |= m == item.pinned;
+            for (Model* m : d->models) served |= voice_usable_by(*item.voice, *m);
             if (!served) { *err = "ptts-hip: voice belongs to a model this dispatcher does not serve"; res->status = PTTS_EINVAL; return PTTS_EINVAL; }
         }
     }

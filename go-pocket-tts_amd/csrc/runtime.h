@@ -115,6 +115,7 @@ struct Voice {
 };
 Voice* voice_create(Model& m, const float* const* caches, const int64_t* steps, const int64_t* offsets);
 void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slots);
+bool voice_usable_by(const Voice& v, const Model& m);   // same GPU and cache geometry (e.g. engines made by model_share)
 
 // buffers of one Mimi decode (all channels-last, spanning the whole utterance so that frame ranges can be decoded in order)
 struct MimiWs {
@@ -137,6 +138,7 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 void step_core(Batch& b, int lsd_steps, bool opened = false);   // opened: x and fx were produced by step_open
 void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev);
+Model* model_share(Model& base);   // another engine over base's weight arena (base must outlive it)
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
 std::string request_error(const Desc& d, const ptts_request& q);   // empty: the request is well formed
 

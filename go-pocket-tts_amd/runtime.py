@@ -86,7 +86,7 @@ ABI_SYMBOLS = [
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
-    "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
+    "ptts_model_share", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
 ]
 
@@ -301,6 +301,13 @@ class Model:
     def open_planned(plan: int, device_arena_ptr: int, fill: bool) -> "Model":
         h = C.c_void_p()
         _check(lib().ptts_model_open_planned(plan, C.c_void_p(device_arena_ptr), 1 if fill else 0, C.byref(h)))
+        return Model(h.value)
+
+    def share(self) -> "Model":
+        """A second engine over this model's weights (own streams, KV caches, workspaces); this model must outlive it."""
+        h = C.c_void_p()
+        lib().ptts_model_share.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        _check(lib().ptts_model_share(self.h, C.byref(h)))
         return Model(h.value)
 
     def close(self):

@@ -143,6 +143,11 @@ typedef struct ptts_result {
     int32_t reserved[2];
 } ptts_result;
 
+/* A second ENGINE over the weights of `base` (its own streams, KV caches, workspaces; the weight arena is shared and
+ * read-only): two engines on one GPU, e.g. behind one dispatcher, let one batch's Mimi decode run beside the next batch's
+ * prefill + AR loop.  `base` must outlive the engine; a device voice belongs to the engine it was uploaded to. */
+int  ptts_model_share(ptts_model* base, ptts_model** out);
+
 /* n_reqs == 1 reproduces GenerateAudio exactly.  n_reqs > 1 is this library's batching
  * extension: independent utterance chunks stepped together (per-row EOS countdown, ragged KV). */
 int  ptts_generate(ptts_model* m, const ptts_request* reqs, int32_t n_reqs, ptts_result* results);

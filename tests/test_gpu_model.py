@@ -591,3 +591,34 @@ def test_service_synthesize_batches_the_chunks_of_a_text(pkg, tiny):
     assert pkg.Service(gm, encode).generate_config(chunks[0]).max_steps == chunks[0].max_frames
     with pytest.raises(pkg.PttsError, match="no tokens produced from input"):
         svc.synthesize("   ")
+
+
+def test_two_engines_share_one_weight_arena(pkg, tiny):
+    """ptts_model_share: a second engine (own streams / caches / workspaces) over the same weights gives bit-identical audio,
+    alone and while the first engine is generating; one dispatcher serves both."""
+    import threading
+    _, _, om, gm = tiny
+    g2 = gm.share()
+    assert g2.info.n_params == gm.info.n_params
+    toks = [np.array([10, 20, 30], np.int64), np.array([4, 5, 6, 7], np.int64)]
+    cfgs = [pkg.RuntimeGenerateConfig(max_steps=4, eos_threshold=1e30, want_latents=True) for _ in toks]
+    a = gm.generate_batch(toks, cfgs)
+    b = g2.generate_batch(toks, cfgs)
+    for x, y in zip(a, b):
+        assert np.array_equal(x.pcm, y.pcm) and np.array_equal(x.latents, y.latents)
+    out = {}
+    ts = [threading.Thread(target=lambda m=m, k=k: out.__setitem__(k, m.generate_batch(toks, cfgs))) for k, m in enumerate((gm, g2))]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    for k in (0, 1):
+        for x, y in zip(a, out[k]):
+            assert np.array_equal(x.pcm, y.pcm)
+    d = pkg.Dispatcher([gm, g2], max_batch=1, window_us=0)
+    res = [None] * 6
+    ts = [threading.Thread(target=lambda i=i: res.__setitem__(i, d.generate(toks[i % 2], cfgs[i % 2]))) for i in range(6)]
+    [t.start() for t in ts]
+    [t.join(60) for t in ts]
+    for i in range(6):   # batches of one here, a batch of two above: equal up to kernel-selection rounding
+        parity(f"dispatch over two engines [{i}]", res[i].pcm, a[i % 2].pcm, (1e-4, 5e-2))
+    d.close()
+    g2.close()

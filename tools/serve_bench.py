@@ -18,18 +18,25 @@ pkg = ptts_amd.load()
 wl = bench.WORKLOADS["b64_10s_bf16"]
 cfg = pkg.synth.SynthConfig.full()
 path = bench.checkpoint_path(pkg, wl["file"], 0, lambda: None)
-model = pkg.Model.open(path, device=0, weights=wl["weights"], kv=wl["kv"], max_batch=64)
-voice = model.upload_voice(pkg.VoiceModelState(bench.voice_modules(pkg, cfg)))
+# PTTS_ENGINES=2: two engines (KV caches, workspaces, streams) over ONE weight arena on the same GPU: batch k+1's prefill and AR
+# loop (latency-bound, most of the chip idle) run beside batch k's Mimi decode (throughput work)
+n_eng = int(os.environ.get("PTTS_ENGINES", "1"))
+kw = dict(device=0, weights=wl["weights"], kv=wl["kv"], max_batch=64)
+models = [pkg.Model.open(path, **kw)]
+models += [models[0].share() for _ in range(n_eng - 1)]
+model = models[0]
+voices = [m.upload_voice(pkg.VoiceModelState(bench.voice_modules(pkg, cfg))) for m in models]
+voice = voices[0]
 prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
 FRAMES, PER_CLIENT = 125, 3
 window_us = int(os.environ.get("PTTS_WINDOW_US", "3000"))
 for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
-    disp = pkg.Dispatcher([model], max_batch=64, window_us=window_us)
+    disp = pkg.Dispatcher(models, max_batch=64, window_us=window_us)
     lat = []
     lock = threading.Lock()
 
     def client(i):
-        c = pkg.RuntimeGenerateConfig(max_steps=FRAMES, eos_threshold=float("inf"), frames_after_eos=3, device_voice=voice, pcm16=True)
+        c = pkg.RuntimeGenerateConfig(max_steps=FRAMES, eos_threshold=float("inf"), frames_after_eos=3, device_voice=voice, pcm16=True)   # one voice: every engine of this GPU can read it
         for k in range(PER_CLIENT):
             t0 = time.perf_counter()
             r = disp.generate(prompts[(i * PER_CLIENT + k) % len(prompts)], c)
@@ -47,9 +54,11 @@ for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
     st = disp.stats()
     audio = clients * PER_CLIENT * FRAMES * bench.FRAME_SEC
     lat.sort()
-    print(f"clients {clients:4d}  window {window_us} us  {audio/wall:8.1f} x real time  latency p50 {1e3*statistics.median(lat):7.1f} ms  "
+    print(f"engines {n_eng} clients {clients:4d}  window {window_us} us  {audio/wall:8.1f} x real time  latency p50 {1e3*statistics.median(lat):7.1f} ms  "
           f"p95 {1e3*lat[int(0.95*(len(lat)-1))]:7.1f} ms  batches {st['batches']:3d}  mean batch {st['mean_batch']:5.1f}  "
           f"mean queue wait {st['mean_wait_us']/1e3:6.1f} ms", flush=True)
     disp.close()
-voice.close()
-model.close()
+for v in voices:
+    v.close()
+for m in reversed(models):
+    m.close()
