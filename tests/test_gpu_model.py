@@ -622,3 +622,15 @@ def test_two_engines_share_one_weight_arena(pkg, tiny):
         parity(f"dispatch over two engines [{i}]", res[i].pcm, a[i % 2].pcm, (1e-4, 5e-2))
     d.close()
     g2.close()
+
+
+def test_long_utterance_beyond_the_one_burst_attention(pkg, tiny):
+    """270 steps at f32 KV: the cache outgrows what k_attn_step holds in one burst (256 keys at f32) and the step falls back
+    to the generic attention kernel with the same fused RoPE + append; latents must keep tracking the oracle."""
+    _, _, om, gm = tiny
+    toks = np.array([10, 20, 30], np.int64)
+    got = gm.generate_batch([toks], [pkg.RuntimeGenerateConfig(max_steps=270, eos_threshold=1e30, want_latents=True)])[0]
+    ref = om.generate(toks, max_steps=270, eos_threshold=1e30, frames_after_eos=3)
+    assert got.n_frames == ref["n_frames"] == 270
+    parity("latents 270 steps", got.latents, ref["latents"], (5e-3, None))
+    parity("pcm 270 steps", got.pcm, ref["pcm"], (1e-2, None))
