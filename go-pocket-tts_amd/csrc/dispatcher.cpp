@@ -46,6 +46,8 @@ struct Dispatcher {
     std::deque<DispatchItem*> queue;
     bool closing = false;
     Clock::time_point last_arrival = Clock::now();
+    Clock::time_point last_batch_left = Clock::now();
+    bool collecting = false;            // one worker at a time forms a batch; the others wait their turn
     std::vector<std::thread> workers;
     // statistics
     int64_t n_requests = 0, n_batches = 0, n_cancelled_waiting = 0, max_depth = 0;
@@ -68,14 +70,16 @@ void Dispatcher::run(int w) {
                 for (DispatchItem* it : queue) if (eligible(it)) return it;
                 return nullptr;
             };
-            cv_work.wait(lock, [&] { return closing || first() != nullptr; });
+            cv_work.wait(lock, [&] { return closing || (!collecting && first() != nullptr); });
             if (closing && first() == nullptr) return;
+            collecting = true;
             // coalescing window: counted from the moment the oldest eligible request arrived, so a lone request waits at
             // most window_us and a full batch leaves at once
             // ... and it stretches (to at most four windows) while requests are still arriving: a burst of callers -- the
             // chunks of one long text, clients released by the previous batch -- trickles in over a few milliseconds, and
             // cutting it in two costs a whole extra batch time (tools/serve_bench.py: 64 clients 5.2 k -> 7.7 k x real time)
-            const Clock::time_point t_first = first()->enq;
+            // what a departing batch left behind gets a fresh window: the callers it is about to release will join it
+            const Clock::time_point t_first = std::max(first()->enq, last_batch_left);
             const auto window = std::chrono::microseconds(window_us), quiet = std::chrono::microseconds(std::max(1, window_us / 4));
             auto n_eligible = [&] { int n = 0; for (DispatchItem* it : queue) n += eligible(it); return n; };
             for (;;) {
@@ -104,6 +108,9 @@ void Dispatcher::run(int w) {
                 sum_wait_us += std::chrono::duration<double, std::micro>(now - d->enq).count();
                 batch.push_back(d);
             }
+            collecting = false;
+            last_batch_left = now;
+            cv_work.notify_all();
             if (batch.empty()) continue;
             n_batches++;
             n_requests += (int64_t)batch.size();

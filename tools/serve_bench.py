@@ -28,7 +28,7 @@ model = models[0]
 voices = [m.upload_voice(pkg.VoiceModelState(bench.voice_modules(pkg, cfg))) for m in models]
 voice = voices[0]
 prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
-FRAMES, PER_CLIENT = 125, 3
+FRAMES, PER_CLIENT = 125, int(os.environ.get("PTTS_PER_CLIENT", "3"))
 window_us = int(os.environ.get("PTTS_WINDOW_US", "3000"))
 for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
     disp = pkg.Dispatcher(models, max_batch=64, window_us=window_us)
