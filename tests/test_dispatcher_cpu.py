@@ -151,3 +151,24 @@ def test_window_stretches_while_requests_keep_arriving(pkg):
     run_clients(d, pkg, 40, stagger=0.008)         # ~320 ms of arrivals: the 200 ms cap cuts the burst
     assert len(batches) >= 2 and sum(len(b) for b in batches) == 40
     d.close()
+
+
+def test_two_workers_do_not_split_a_trickle(pkg):
+    """Two workers finish together and find six requests that have waited longer than a window: the first takes a full
+    batch, and the two it leaves behind get a FRESH window (late arrivals join them) instead of leaving at once as a sliver."""
+    batches = []
+    d = pkg.Dispatcher([], max_batch=4, window_us=100_000, _custom_exec=make_exec(batches, delay=0.2), _workers=2)
+    res = {}
+
+    def wave(n, at):
+        time.sleep(at)
+        res[at] = run_clients(d, pkg, n)
+
+    ts = [threading.Thread(target=wave, args=a) for a in ((8, 0.0), (6, 0.05), (2, 0.23))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(30)
+    assert all(not any(errs) for _, errs in res.values())
+    assert sorted(len(b) for b in batches) == [4, 4, 4, 4], batches
+    d.close()
