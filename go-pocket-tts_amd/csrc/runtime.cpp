@@ -666,7 +666,8 @@ static void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
 
 // frames [f0, f1) of every utterance; lat: device [B][*][ldim] with lat_bstride elements between utterances;
 // pcm: device [B][T * samples_per_frame]; mimi_latent (optional): [B][C][T] (whole range only)
-void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s) {
+void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
+                int final_groups, const std::function<void(int, int)>* after_group) {
     const Desc& d = m.d;
     const int B = w.B, T = w.T, C = d.mimi_dim, S = d.up_stride, T1 = T * S, F = d.mimi_ffn, P0 = w.P0;
     if (f1 <= f0) return;
@@ -762,7 +763,20 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
                 ra.pcm = pcm; ra.pcm_bs = w.Ls[3];
             }
             if (d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 == d.rb2[j].bf16 && resblock_supported(ra)) {
-                launch_resblock(ra, s);
+                if (j == 2 && final_groups > 1 && after_group) {
+                    // the launch that produces the samples runs per group of utterances, so that the caller can start moving
+                    // a group's audio to the host while the next group is computed
+                    const int per = (B + final_groups - 1) / final_groups;
+                    for (int b0 = 0; b0 < B; b0 += per) {
+                        const int b1 = std::min(B, b0 + per);
+                        ResArgs rg = ra;
+                        rg.u = ra.u + (int64_t)b0 * ra.u_bs; rg.pcm = ra.pcm + (int64_t)b0 * ra.pcm_bs; rg.B = b1 - b0;
+                        launch_resblock(rg, s);
+                        (*after_group)(b0, b1);
+                    }
+                } else {
+                    launch_resblock(ra, s);
+                }
                 if (j == 2) final_done = true;
                 continue;
             }
@@ -1035,13 +1049,18 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     }
     int f_done = 0, f_emitted = 0, steps_run = 0;
     size_t ev_used = 0;
+    auto next_event = [&]() {
+        if (m.events.size() <= ev_used) { hipEvent_t e; PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.events.push_back(e); }
+        return m.events[ev_used++];
+    };
+    int final_groups = 1;
+    const std::function<void(int, int)>* after_group = nullptr;
     auto decode_upto = [&](int f1) {
         if (f1 <= f_done) return;
-        if (m.events.size() <= ev_used) { hipEvent_t e; PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.events.push_back(e); }
-        hipEvent_t e = m.events[ev_used++];
+        hipEvent_t e = next_event();
         PTTS_HIP(hipEventRecord(e, s));
         PTTS_HIP(hipStreamWaitEvent(m.stream2, e, 0));
-        mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2);
+        mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2, final_groups, after_group);
         f_done = f1;
     };
     auto emit_upto = [&](int f1) {   // hand frames [f_emitted, f1) to the streaming callbacks (they are decoded: f1 <= f_done)
@@ -1112,22 +1131,13 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     int Tmax = 0;
     for (int i = 0; i < B; i++) if (!cancelled[i]) Tmax = std::max(Tmax, nf[i]);
     if (Tmax > 0) {
-        decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
-        emit_upto(std::min(steps_run, Tmax));
-        PTTS_HIP(hipStreamSynchronize(m.stream2));
-        for (int32_t* p : stream_nf) (void)hipHostFree(p);
-        stream_nf.clear();
         DevBuf* pcm_s16 = nullptr;   // PCM16 egress on the device (audio/wav_stream.go:43-54) for the requests that ask for it
-        {
-            bool any_s16 = false;
-            for (int i = 0; i < B; i++) any_s16 |= reqs[idx[i]].pcm_format == PTTS_PCM_S16 && !cancelled[i];
-            if (any_s16) {
-                pcm_s16 = &m.work(8, (size_t)B * T * spf * sizeof(int16_t));
-                launch_pcm16(pcm.as<float>(), pcm_s16->as<int16_t>(), (int64_t)B * T * spf, s);
-            }
-        }
-        mark("mimi");
-        for (int i = 0; i < B; i++) {
+        bool any_s16 = false;
+        for (int i = 0; i < B; i++) any_s16 |= reqs[idx[i]].pcm_format == PTTS_PCM_S16 && !cancelled[i] && !stream_host[(size_t)i];
+        if (any_s16) pcm_s16 = &m.work(8, (size_t)B * T * spf * sizeof(int16_t));
+        // results of utterances [b0, b1): buffers, and the copies queued on s
+        auto finish_rows = [&](int b0, int b1) {
+        for (int i = b0; i < b1; i++) {
             ptts_result& r = res[idx[i]];
             if (cancelled[i]) { fail_req(r, PTTS_ECANCELLED); continue; }
             r.n_frames = nf[i];
@@ -1154,6 +1164,33 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
                 d2h(r.latents, b.latents.as<float>() + (size_t)i * b.max_steps * ld, (size_t)nf[i] * ld * sizeof(float), s);
             }
             r.status = PTTS_OK;
+        }
+        };
+        // Whole batch decoded in one go (the default): the launch that writes the samples is cut into groups of utterances and
+        // each group's device->host copies are queued (on s) behind it, so that the PCIe transfer of one group runs under the
+        // kernel of the next; only the last group's copies are exposed.
+        const bool grouped = !streaming && f_done == 0 && B >= 8;
+        int rows_finished = 0;   // stays 0 when the decoder took a path without the grouped launch
+        std::function<void(int, int)> on_group = [&](int b0, int b1) {
+            rows_finished += b1 - b0;
+            if (pcm_s16) launch_pcm16(pcm.as<float>() + (size_t)b0 * T * spf, pcm_s16->as<int16_t>() + (size_t)b0 * T * spf, (int64_t)(b1 - b0) * T * spf, m.stream2);
+            hipEvent_t e = next_event();
+            PTTS_HIP(hipEventRecord(e, m.stream2));
+            PTTS_HIP(hipStreamWaitEvent(s, e, 0));
+            finish_rows(b0, b1);
+        };
+        if (grouped) { final_groups = 4; after_group = &on_group; }
+        decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
+        final_groups = 1; after_group = nullptr;
+        emit_upto(std::min(steps_run, Tmax));
+        const bool rows_done = rows_finished == B;
+        PTTS_HIP(hipStreamSynchronize(m.stream2));
+        for (int32_t* p : stream_nf) (void)hipHostFree(p);
+        stream_nf.clear();
+        mark("mimi");
+        if (!rows_done) {
+            if (pcm_s16) launch_pcm16(pcm.as<float>(), pcm_s16->as<int16_t>(), (int64_t)B * T * spf, s);
+            finish_rows(0, B);
         }
         PTTS_HIP(hipStreamSynchronize(s));
         mark("results d2h");

@@ -126,7 +126,10 @@ struct MimiWs {
     bool zeroed = false;
 };
 void mimi_setup(Model& m, MimiWs& w, int B, int T);
-void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s);
+// final_groups > 1 with after_group: the launch that writes the samples is issued per group of utterances and
+// after_group(b0, b1) is called (on the host, at enqueue time) behind each, so the caller can queue that group's copies
+void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
+                int final_groups = 1, const std::function<void(int, int)>* after_group = nullptr);
 
 Model* model_open(Plan* plan, void* device_arena, int fill);
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);
