@@ -1,5 +1,7 @@
 // attn_window.hip -- sliding-window self-attention of the Mimi decoder transformer (K15; mimi.go:365-441,
 // attention.go:307-484 with context 250: a query at position p sees keys p-249 .. p of its own utterance).
+#include <type_traits>
+
 #include "kernels.h"
 #include "device_util.h"
 
@@ -21,6 +23,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // the end.  Keys are fetched straight from the qkv rows in HBM/L2 (each K row half is 128 contiguous bytes per lane,
 // each V fetch is two 128-byte row pieces per instruction); a block is 4 waves = 4 neighbouring query tiles so their
 // overlapping windows meet in L1/L2.  Sums are in a fixed order: results are bitwise reproducible.
+//
+// The same kernel serves the prompt prefill of the FlowLM transformer (flow_transformer.go:749-771; RAGGED): the queries of
+// segment s are the packed rows [rag_off[s], rag_off[s+1]) at positions rag_pos0[s] + i, the keys are the segment's cache rows
+// 0 .. position (context < 0: no window), stored as f32 or bf16 (KVBF16: widened on load, f32 arithmetic as above).
+template <bool KVBF16, bool RAGGED>
 __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int h = blockIdx.x;
@@ -28,14 +35,18 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     const int seg = blockIdx.y / groups, qt = (blockIdx.y % groups) * 4 + wave;
     if (qt >= qtiles) return;   // whole wave; the kernel has no block-level synchronisation
     const int r0 = qt * 32;
-    const int nq = min(32, a.rows_per_seg - r0);
+    const int seg_row0 = RAGGED ? a.rag_off[seg] : seg * a.rows_per_seg;
+    const int seg_rows = RAGGED ? a.rag_off[seg + 1] - seg_row0 : a.rows_per_seg;
+    if (r0 >= seg_rows) return;
+    const int nq = min(32, seg_rows - r0);
     const int j = lane & 31, half = lane >> 5;
     const int my_q = min(j, nq - 1);                 // lanes past a ragged end replay the last query and store nothing
-    const int p_first = a.pos_base + r0, p_last = p_first + nq - 1;
+    const int p_first = (RAGGED ? a.rag_pos0[seg] : a.pos_base) + r0, p_last = p_first + nq - 1;
     const int my_pos = p_first + my_q;
-    const int j_lo = max(0, p_first - a.context + 1);
+    const int ctx = a.context > 0 ? a.context : (1 << 30);
+    const int j_lo = max(0, p_first - ctx + 1);
     const RowMap qm{a.q_ld, a.q_rows_per_batch, a.q_batch_stride}, om{a.out_ld, a.o_rows_per_batch, a.o_batch_stride};
-    const int row = seg * a.rows_per_seg + r0 + my_q;
+    const int row = seg_row0 + r0 + my_q;
 
     float q[32];
     {
@@ -46,8 +57,9 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
             q[4 * i] = t.x * 0.125f; q[4 * i + 1] = t.y * 0.125f; q[4 * i + 2] = t.z * 0.125f; q[4 * i + 3] = t.w * 0.125f;   // 1/sqrt(64), exact
         }
     }
-    const float* kb = (const float*)a.k + (int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride;
-    const float* vb = (const float*)a.v + (int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride;
+    typedef typename std::conditional<KVBF16, unsigned short, float>::type KvT;
+    const KvT* kb = (const KvT*)a.k + (int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride;
+    const KvT* vb = (const KvT*)a.v + (int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride;
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; r++) { o0[r] = 0.0f; o1[r] = 0.0f; }
@@ -56,20 +68,36 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     for (int kt = j_lo; kt <= p_last; kt += 32) {
         float kr[32];
         {
-            const float* kp = kb + (int64_t)min(kt + j, p_last) * a.k_row_stride + half * 32;
+            const KvT* kp = kb + (int64_t)min(kt + j, p_last) * a.k_row_stride + half * 32;
+            if constexpr (KVBF16) {
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const float4 t = *reinterpret_cast<const float4*>(kp + i * 4);
-                kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
+                for (int i = 0; i < 4; i++) {
+                    const uint4 t = *reinterpret_cast<const uint4*>(kp + i * 8);   // 8 bf16: element e is the low half of word e/2 for even e
+                    kr[8 * i] = __uint_as_float(t.x << 16); kr[8 * i + 1] = __uint_as_float(t.x & 0xffff0000u);
+                    kr[8 * i + 2] = __uint_as_float(t.y << 16); kr[8 * i + 3] = __uint_as_float(t.y & 0xffff0000u);
+                    kr[8 * i + 4] = __uint_as_float(t.z << 16); kr[8 * i + 5] = __uint_as_float(t.z & 0xffff0000u);
+                    kr[8 * i + 6] = __uint_as_float(t.w << 16); kr[8 * i + 7] = __uint_as_float(t.w & 0xffff0000u);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const float4 t = *reinterpret_cast<const float4*>(kp + i * 4);
+                    kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
+                }
             }
         }
         float v0[16], v1[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int key = min(kt + (r & 3) + 8 * (r >> 2) + 4 * half, p_last);
-            const float* vp = vb + (int64_t)key * a.k_row_stride + j;
-            v0[r] = vp[0];
-            v1[r] = vp[32];
+            const KvT* vp = vb + (int64_t)key * a.k_row_stride + j;
+            if constexpr (KVBF16) {
+                v0[r] = __uint_as_float((unsigned)vp[0] << 16);
+                v1[r] = __uint_as_float((unsigned)vp[32] << 16);
+            } else {
+                v0[r] = vp[0];
+                v1[r] = vp[32];
+            }
         }
         f32x16 s;
 #pragma unroll
@@ -80,7 +108,7 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const bool ok = key <= my_pos && key > my_pos - a.context;
+            const bool ok = key <= my_pos && key > my_pos - ctx;
             s[r] = ok ? s[r] : -INFINITY;
             tmax = fmaxf(tmax, s[r]);
         }
@@ -116,15 +144,25 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
 }
 
 bool attn_window_supported(const AttnArgs& a) {
-    return !a.fused_step && !a.kv_bf16 && a.hd == 64 && a.context > 0 && a.rows_per_seg > 0 && !a.row_seg && !a.row_pos && !a.seg_len &&
-           !a.active && a.rows % a.rows_per_seg == 0 && a.k_row_stride % 4 == 0 && a.k_head_stride % 4 == 0 && a.q_ld % 4 == 0 &&
-           a.out_ld % 4 == 0;
+    const bool ragged = a.rag_off != nullptr;
+    const int kalign = a.kv_bf16 ? 8 : 4;   // 16-byte key loads
+    if (a.fused_step || a.hd != 64 || a.rows_per_seg <= 0 || a.seg_len || a.active || a.k_row_stride % kalign || a.k_head_stride % kalign ||
+        a.k_seg_stride % kalign || a.q_ld % 4 || a.out_ld % 4 || !aligned16(a.k) || !aligned16(a.q) || !aligned16(a.out))
+        return false;
+    if (ragged) return a.rag_pos0 && a.rag_segs > 0 && a.q_rows_per_batch == 0 && a.o_rows_per_batch == 0;   // packed rows
+    return !a.kv_bf16 && a.context > 0 && !a.row_seg && !a.row_pos && a.rows % a.rows_per_seg == 0;
 }
 
 void launch_attn_window(const AttnArgs& a, hipStream_t stream) {
-    const int qtiles = (a.rows_per_seg + 31) / 32;
-    dim3 grid(a.heads, (unsigned)((a.rows / a.rows_per_seg) * ((qtiles + 3) / 4)));
-    hipLaunchKernelGGL(k_attn_window, grid, dim3(256), 0, stream, a, qtiles);
+    const int qtiles = (a.rows_per_seg + 31) / 32;   // ragged: rows_per_seg is the longest segment
+    const int segs = a.rag_off ? a.rag_segs : a.rows / a.rows_per_seg;
+    dim3 grid(a.heads, (unsigned)(segs * ((qtiles + 3) / 4)));
+    if (a.rag_off) {
+        if (a.kv_bf16) hipLaunchKernelGGL((k_attn_window<true, true>), grid, dim3(256), 0, stream, a, qtiles);
+        else hipLaunchKernelGGL((k_attn_window<false, true>), grid, dim3(256), 0, stream, a, qtiles);
+    } else {
+        hipLaunchKernelGGL((k_attn_window<false, false>), grid, dim3(256), 0, stream, a, qtiles);
+    }
 }
 
 }  // namespace ptts

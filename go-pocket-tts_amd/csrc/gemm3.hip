@@ -59,10 +59,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
     const int pan = (jb / ncol) * 8 + xcd;
     if (pan >= npan) return;
     const int m0 = pan * G3_BM + wave * 32, n0 = (jb % ncol) * BN;
+    // split-K (a.kslice > 0): blockIdx.y owns k in [kz, kz + KL) and writes its raw sums to plane blockIdx.y of C
+    const int kz = blockIdx.y * a.kslice;
+    const int KL = a.kslice ? min(a.kslice, a.K - kz) : a.K;
 
     const float* aptr[2];
 #pragma unroll
-    for (int t = 0; t < 2; t++) aptr[t] = a.A + row_off(a.amap, min(m0 + t * 16 + r16, a.M - 1)) + g * 8;
+    for (int t = 0; t < 2; t++) aptr[t] = a.A + row_off(a.amap, min(m0 + t * 16 + r16, a.M - 1)) + kz + g * 8;
 
     uint4 wreg[PPT];
     auto w_load = [&](int c) {
@@ -73,8 +76,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
             const int n = pc / PPR;
             const int k = k0 + (pc % PPR) * (WBF16 ? 8 : 4);
             uint4 u = make_uint4(0, 0, 0, 0);
-            if (pc < PIECES && n0 + n < a.N && k < a.K)
-                u = *reinterpret_cast<const uint4*>((const char*)a.W + ((int64_t)(n0 + n) * a.ldw + k) * (WBF16 ? 2 : 4));
+            if (pc < PIECES && n0 + n < a.N && k < KL)
+                u = *reinterpret_cast<const uint4*>((const char*)a.W + ((int64_t)(n0 + n) * a.ldw + kz + k) * (WBF16 ? 2 : 4));
             wreg[p] = u;
         }
     };
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; n++) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = a.K >> 5, nchunks = (a.K + G3_CH - 1) / G3_CH;
+    const int nsteps = KL >> 5, nchunks = (KL + G3_CH - 1) / G3_CH;
     // activations: a ring of SPC 32-k steps per wave.  The slot of step i is refilled with step i + SPC as soon as step i
     // has been split into fragments, so every wave keeps SPC steps (CH k of its 32 rows) in flight at all times.
     float4 av[SPC][2][2];
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
     for (int t = 0; t < 2; t++) {
         const int m = m0 + t * 16 + r16;
         if (m >= a.M) continue;
-        const int64_t ro = row_off(a.cmap, m);
+        const int64_t ro = row_off(a.cmap, m) + blockIdx.y * a.zstride;
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int col = n0 + n * 16 + 4 * g;
@@ -180,7 +183,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             }
             if (a.rope_cos && col < a.rope_cols) {   // the lane's four columns are two (even, odd) pairs of one head
-                const int pos = a.rope_pos0 + (a.rope_rows_per_seg ? m % a.rope_rows_per_seg : m);
+                const int pos = a.rope_row_pos ? a.rope_row_pos[m] : a.rope_pos0 + (a.rope_rows_per_seg ? m % a.rope_rows_per_seg : m);
                 const int half = a.rope_hd >> 1, j = (col % a.rope_hd) >> 1;
                 const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (int64_t)pos * half + j);
                 const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (int64_t)pos * half + j);
@@ -228,13 +231,14 @@ bool gemm3_supported(const GemmArgs& a) {
            a.ldw % kalign == 0 && aligned16(a.W) && aligned16(a.C) && a.cmap.ld % 4 == 0 && a.cmap.batch_stride % 4 == 0 &&
            (!a.bias || aligned16(a.bias)) && (!a.addvec || aligned16(a.addvec)) && (!a.scale || aligned16(a.scale)) &&
            (!res || aligned16(a.R)) && (a.epi != EPI_GATE_RESADD || (aligned16(a.gate) && a.ldg % 4 == 0)) &&
-           (!a.rope_cos || (a.rope_hd % 4 == 0 && a.rope_cols % 4 == 0 && a.epi == EPI_NONE));
+           (!a.rope_cos || (a.rope_hd % 4 == 0 && a.rope_cols % 4 == 0 && a.epi == EPI_NONE)) &&
+           (!a.kslice || (a.kslice % 128 == 0 && a.epi == EPI_NONE && !a.bias && !a.rope_cos && a.zstride % 4 == 0));
 }
 
 template <int BN, int NW, int CH>
 static void launch3_cfg(const GemmArgs& a, hipStream_t stream) {
     const int ncol = (a.N + BN - 1) / BN, npan = (a.M + NW * 32 - 1) / (NW * 32);
-    dim3 grid((unsigned)(((npan + 7) / 8) * 8 * ncol));
+    dim3 grid((unsigned)(((npan + 7) / 8) * 8 * ncol), (unsigned)(a.kslice ? (a.K + a.kslice - 1) / a.kslice : 1));
     if (a.w_bf16) hipLaunchKernelGGL((k_gemm3<BN, true, NW, CH>), grid, dim3(NW * 64), 0, stream, a);
     else hipLaunchKernelGGL((k_gemm3<BN, false, NW, CH>), grid, dim3(NW * 64), 0, stream, a);
 }
@@ -256,8 +260,10 @@ static void launch3_bn(const GemmArgs& a, hipStream_t stream) {
 // loads per MFMA and win from N = 512 up (K = 512: +7..17 %, K >= 1024: +21..29 %); at N = 256 the two are level.
 void launch_gemm3(const GemmArgs& a, hipStream_t stream) {
     const bool wide = g_gemm3_cfg == 4 || (g_gemm3_cfg == 0 && a.N >= 512 && a.M >= 16384);
+    // few row panels (the prompt prefill: ~1600 rows): 128-column blocks would cover under 80 % of the CUs -- halve the block's columns
+    const bool narrow = g_gemm3_cfg == 0 && a.M < 16384 && ((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.kslice ? (a.K + a.kslice - 1) / a.kslice : 1) < 200;
     if (wide && a.N >= 256) launch3_cfg<256, 8, 64>(a, stream);
-    else if (a.N > 64) launch3_bn<128>(a, stream);
+    else if (a.N > 64 && !narrow) launch3_bn<128>(a, stream);
     else if (a.N > 32) launch3_bn<64>(a, stream);
     else launch3_bn<32>(a, stream);
 }

@@ -45,6 +45,10 @@ struct GemmArgs {
     // k_gemm3 only: interleaved-pair RoPE (rope.go:81-105) applied to the first rope_cols output columns before they are
     // stored (q and k of a qkv projection); row m sits at position rope_pos0 + m % rope_rows_per_seg (0: m)
     const float* rope_cos = nullptr; const float* rope_sin = nullptr; int rope_cols = 0, rope_hd = 64, rope_pos0 = 0, rope_rows_per_seg = 0;
+    const int32_t* rope_row_pos = nullptr;   // if set: the position of row m is rope_row_pos[m] (ragged prompt rows)
+    // k_gemm3 only: split-K.  kslice > 0: ceil(K / kslice) blocks share an output tile, block z multiplies k in
+    // [z kslice, (z+1) kslice) and stores its raw sums at C + z * zstride (no bias, no epilogue: the consumer adds the planes)
+    int kslice = 0; int64_t zstride = 0;
     float* tail = nullptr;           // k_skinny only: the LAST column goes, as acc + bias without the epilogue, to tail[m] instead of C
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
@@ -141,6 +145,9 @@ struct AttnArgs {
     // fused step only: keys j < pre_len[seg] are read from a shared prefix (a device voice, [layer][head][pre_len][hd] in the
     // cache dtype) instead of the segment's own cache rows
     const void* const* pre_k = nullptr; const void* const* pre_v = nullptr; const int32_t* pre_len = nullptr; int layer = 0;
+    // ragged segments (prompt prefill on the matrix cores, attn_window.hip): rows of segment s are the packed rows
+    // [rag_off[s], rag_off[s+1]) at positions rag_pos0[s] + i; rows_per_seg is then the longest segment
+    const int32_t* rag_off = nullptr; const int32_t* rag_pos0 = nullptr; int rag_segs = 0;
 };
 void launch_attention(const AttnArgs& a, hipStream_t stream);   // picks k_attn_step for the fused AR step when the cache fits one burst
 bool attn_step_supported(const AttnArgs& a);

@@ -322,11 +322,22 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
         }
     }
     const size_t f = sizeof(float);
-    DevBuf& idx = m.work(2, (size_t)2 * R * sizeof(int32_t));
+    // one upload: row -> slot, row -> position, and per slot the first row / first position (the ragged-segment view of the same)
+    std::vector<int32_t> meta((size_t)2 * R + 2 * B + 1);
+    std::copy(row_slot.begin(), row_slot.end(), meta.begin());
+    std::copy(row_pos.begin(), row_pos.end(), meta.begin() + R);
+    int max_rows = 0;
+    for (int sl = 0; sl <= B; sl++) meta[(size_t)2 * R + sl] = (int32_t)row_offsets[sl];
+    for (int sl = 0; sl < B; sl++) {
+        meta[(size_t)2 * R + B + 1 + sl] = b.kv_len_host[sl];
+        max_rows = std::max(max_rows, (int)(row_offsets[sl + 1] - row_offsets[sl]));
+    }
+    DevBuf& idx = m.work(2, meta.size() * sizeof(int32_t));
     int32_t* d_slot = idx.as<int32_t>();
     int32_t* d_pos = d_slot + R;
-    h2d(d_slot, row_slot.data(), (size_t)R * sizeof(int32_t), s);
-    h2d(d_pos, row_pos.data(), (size_t)R * sizeof(int32_t), s);
+    const int32_t* d_off = d_pos + R;
+    const int32_t* d_pos0 = d_off + B + 1;
+    h2d(d_slot, meta.data(), meta.size() * sizeof(int32_t), s);
     DevBuf& wsb = m.work(3, ((size_t)R * (size_t)(D + D + 3 * D + D + d.ffn)) * f);
     float* px = wsb.as<float>();
     float* pxn = px + (size_t)R * D;
@@ -348,9 +359,18 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
             launch_layernorm(ln, s);
             pend_partial = nullptr; pend_split = 0;
         }
-        launch_gemm(mk(m, pxn, flat(D), L.in_proj, pqkv, flat(3 * D), R), s);
-        launch_rope_rows(pqkv, flat(3 * D), 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
-        launch_rope_rows(pqkv, flat(3 * D), D, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        {
+            GemmArgs gq = mk(m, pxn, flat(D), L.in_proj, pqkv, flat(3 * D), R);
+            gq.rope_cos = m.at<float>(d.rope_cos); gq.rope_sin = m.at<float>(d.rope_sin);   // q and k are rotated in the epilogue
+            gq.rope_cols = 2 * D; gq.rope_hd = d.hd; gq.rope_row_pos = d_pos;
+            if (gemm3_supported(gq)) launch_gemm3(gq, s);
+            else {
+                gq.rope_cos = gq.rope_sin = nullptr; gq.rope_row_pos = nullptr;
+                launch_gemm(gq, s);
+                launch_rope_rows(pqkv, flat(3 * D), 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+                launch_rope_rows(pqkv, flat(3 * D), D, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+            }
+        }
         launch_kv_append(pqkv, 3 * D, D, d.heads, d.hd, d_slot, d_pos, R, b.kc(l), b.vc(l), kvb, b.cap, s);
         if (l == d.n_layers - 1) break;
         AttnArgs a;
@@ -358,6 +378,7 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
         a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
         a.k_seg_stride = (int64_t)d.heads * b.cap * d.hd; a.k_head_stride = (int64_t)b.cap * d.hd; a.k_row_stride = d.hd;
         a.row_seg = d_slot; a.row_pos = d_pos;
+        a.rag_off = d_off; a.rag_pos0 = d_pos0; a.rag_segs = B; a.rows_per_seg = max_rows;
         a.context = -1;
         a.out = pattn; a.out_ld = D;
         a.rows = R; a.heads = d.heads; a.max_keys = max_pos + 1;
@@ -376,6 +397,20 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
             launch_skinny(g2, SkinnyFuse{}, S, pb.as<float>(), s);
             pend_partial = pb.as<float>(); pend_split = S; pend_bias = m.at<float>(L.l2.b);
         } else {
+            // many rows, few row panels: a 4 d_model-deep product on ~100-200 blocks leaves one wave per SIMD waiting on its own
+            // loads -- cut K in four (four times the blocks) and let the next layer's LayerNorm launch add the planes
+            GemmArgs gs = g2;
+            gs.bias = nullptr; gs.kslice = 1024; gs.zstride = (int64_t)R * D;
+            const int Sg = (d.ffn + gs.kslice - 1) / gs.kslice;
+            if (R < 16384 && Sg > 1 && Sg <= 8) {
+                DevBuf& pb = m.work(9, (size_t)Sg * R * D * f);
+                gs.C = pb.as<float>(); gs.cmap = flat(D);
+                if (gemm3_supported(gs)) {
+                    launch_gemm3(gs, s);
+                    pend_partial = pb.as<float>(); pend_split = Sg; pend_bias = m.at<float>(L.l2.b);
+                    continue;
+                }
+            }
             g2.R = px; g2.epi = EPI_RESADD;
             launch_gemm(g2, s);
         }
@@ -974,15 +1009,27 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         for (int i = 0; i < B; i++) ids.insert(ids.end(), reqs[idx[i]].tokens, reqs[idx[i]].tokens + reqs[idx[i]].n_tokens);
         DevBuf& dids = m.work(6, ids.size() * sizeof(int64_t));
         h2d(dids.p, ids.data(), ids.size() * sizeof(int64_t), s);
-        int64_t id0 = 0;
+        // token rows of consecutive requests are contiguous unless a voice embedding sits between them: one gather per such run
+        // (a batch without voice embeddings is ONE launch instead of one per request)
+        int64_t id0 = 0, run_id0 = 0, run_n = 0;
+        float* run_dst = rows.as<float>();
+        auto flush = [&]() {
+            if (run_n > 0) launch_embed_gather(m.at<float>(d.embed), dids.as<int64_t>() + run_id0, (int)run_n, D, run_dst, s);
+            run_n = 0;
+        };
         for (int i = 0; i < B; i++) {
             const ptts_request& r = reqs[idx[i]];
             float* dst = rows.as<float>() + row_off[i] * D;
             int64_t tv = r.voice_embedding ? r.voice_frames : 0;
-            if (tv) h2d(dst, r.voice_embedding, (size_t)tv * D * sizeof(float), s);
-            launch_embed_gather(m.at<float>(d.embed), dids.as<int64_t>() + id0, (int)r.n_tokens, D, dst + tv * D, s);
+            if (tv) {
+                flush();
+                h2d(dst, r.voice_embedding, (size_t)tv * D * sizeof(float), s);
+            }
+            if (run_n == 0) { run_id0 = id0; run_dst = dst + tv * D; }
+            run_n += r.n_tokens;
             id0 += r.n_tokens;
         }
+        flush();
     }
     mark("setup");
     batch_prompt(b, rows.as<float>(), row_off.data());

@@ -634,3 +634,34 @@ def test_long_utterance_beyond_the_one_burst_attention(pkg, tiny):
     assert got.n_frames == ref["n_frames"] == 270
     parity("latents 270 steps", got.latents, ref["latents"], (5e-3, None))
     parity("pcm 270 steps", got.pcm, ref["pcm"], (1e-2, None))
+
+
+@pytest.mark.parametrize("kv", ["f32", "bf16"])
+def test_prefill_ragged_long_prompts_on_the_matrix_cores(pkg, tiny, kv):
+    """Prompt prefill attention (flow_transformer.go:749-771) as ragged segments on the f32 matrix cores: prompts of 70, 5
+    and 33 rows (several query tiles, ragged ends), one slot on top of a 9-key voice state; every key/value the prefill leaves
+    in the cache against the oracle's (layer l's keys depend on layer l-1's attention output)."""
+    cfg, path, om, gm = tiny
+    own = None
+    if kv == "bf16":
+        own = gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_F32, kv=pkg.KV_BF16)
+    tol = FLOW_TOL if kv == "f32" else (3e-2, None)   # bf16 cache: 8-bit mantissa keys/values, max-norm bound only
+    rng = np.random.default_rng(7)
+    lens = [70, 5, 33]
+    embs = [om.text_embeddings(rng.integers(0, cfg.n_bins, n)) for n in lens]
+    mods = _modules(pkg.synth.make_voice_state(cfg, offset=9, capacity=16))
+    b = gm.new_batch(3, 128)
+    b.set_voice_state(2, pkg.VoiceModelState(mods))
+    b.prompt(embs)
+    assert list(b.offsets()) == [70, 5, 33 + 9]
+    for slot, emb in enumerate(embs):
+        st = om.state_from_voice(mods) if slot == 2 else om.new_state()
+        om.prompt(st, emb)
+        for layer in range(om.n_layers):
+            ko, vo = st.kv(layer)
+            kg, vg = b.read_kv(slot, layer)
+            parity(f"slot {slot} K layer {layer}", kg, ko, tol)
+            parity(f"slot {slot} V layer {layer}", vg, vo, tol)
+    b.close()
+    if own:
+        own.close()
