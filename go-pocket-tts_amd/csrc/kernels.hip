@@ -470,8 +470,36 @@ void launch_attention(const AttnArgs& a, hipStream_t stream) {
 // Mimi front end
 // ------------------------------------------------------------------------------------------------
 // K13: latent -> mimi projector with emb_std/emb_mean folded in (model.go:226-242,294-303)
-__global__ void k_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
-                            int ldim, int c, float* out) {
+// A thread owns one output channel and keeps its weight row in registers; a block walks PROJ_ROWS frames, whose latent rows are
+// wave-uniform (scalar loads feeding v_fmac).  The k order of the sum is the reference's.
+constexpr int PROJ_ROWS = 16, PROJ_LMAX = 64;
+__global__ __launch_bounds__(256) void k_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
+                                                   int ldim, int c, float* out) {
+    const int oc = blockIdx.x * 256 + threadIdx.x;
+    const int nf = f1 - f0;
+    const int ocl = min(oc, c - 1);
+    float w[PROJ_LMAX];
+#pragma unroll
+    for (int k = 0; k < PROJ_LMAX; k += 4) {
+        if (k < ldim) {   // ldim % 4 == 0 (host)
+            const float4 v = *reinterpret_cast<const float4*>(wp + (int64_t)ocl * ldim + k);
+            w[k] = v.x; w[k + 1] = v.y; w[k + 2] = v.z; w[k + 3] = v.w;
+        }
+    }
+    const float bias = bp[ocl];
+    const int row0 = blockIdx.y * PROJ_ROWS, row1 = min(row0 + PROJ_ROWS, b * nf);
+    for (int row = row0; row < row1; row++) {
+        const int bi = row / nf, f = f0 + row % nf;
+        const float* l = latent + (int64_t)bi * lat_bstride + (int64_t)f * ldim;
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < PROJ_LMAX; k++)
+            if (k < ldim) s += l[k] * w[k];
+        if (oc < c) out[((int64_t)bi * (t + 1) + 1 + f) * c + oc] = s + bias;   // row 0 of every utterance is the zero history row
+    }
+}
+__global__ void k_projector_any(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
+                                int ldim, int c, float* out) {   // any ldim
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nf = f1 - f0;
     int64_t tot = (int64_t)b * nf * c;
@@ -483,16 +511,42 @@ __global__ void k_projector(const float* latent, int64_t lat_bstride, const floa
     const float* w = wp + (int64_t)oc * ldim;
     float s = 0.0f;
     for (int k = 0; k < ldim; k++) s += l[k] * w[k];
-    out[((int64_t)bi * (t + 1) + 1 + f) * c + oc] = s + bp[oc];   // row 0 of every utterance is the zero history row
+    out[((int64_t)bi * (t + 1) + 1 + f) * c + oc] = s + bp[oc];
 }
 void launch_projector(const float* latent, int64_t lat_bstride, const float* wp, const float* bp, int b, int t, int f0, int f1,
                       int ldim, int c, float* out, hipStream_t stream) {
     int64_t tot = (int64_t)b * (f1 - f0) * c;
     if (tot <= 0) return;
-    hipLaunchKernelGGL(k_projector, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, latent, lat_bstride, wp, bp, b, t, f0, f1, ldim, c, out);
+    if (ldim <= PROJ_LMAX && ldim % 4 == 0 && aligned16(wp)) {
+        const int rows = b * (f1 - f0);
+        hipLaunchKernelGGL(k_projector, dim3((unsigned)((c + 255) / 256), (unsigned)((rows + PROJ_ROWS - 1) / PROJ_ROWS)), dim3(256), 0, stream, latent, lat_bstride,
+                           wp, bp, b, t, f0, f1, ldim, c, out);
+        return;
+    }
+    hipLaunchKernelGGL(k_projector_any, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, latent, lat_bstride, wp, bp, b, t, f0, f1, ldim, c, out);
 }
 
 // K14: depthwise transposed conv, k = 2*stride, first T*stride outputs kept (convtranspose1d.go:154-202, mimi.go:116-125)
+// One block per input frame: a thread owns four channels, reads frame t-1 and frame t once and writes the frame's `stride`
+// output rows (no per-element index arithmetic; every access is a coalesced float4).
+__global__ __launch_bounds__(128) void k_upsample_dw4(const float* in, const float* w0, const float* w1, const float* bias, int t, int f0, int nf, int c,
+                                                     int stride, float* out, int pad) {
+    const int bi = blockIdx.x / nf, tt = f0 + blockIdx.x % nf;
+    const float* x = in + ((int64_t)bi * (t + 1) + tt) * c;   // x[0..c) = frame t-1 (row 0 is the zero row), x[c..2c) = frame t
+    float* o = out + ((int64_t)bi * (pad + (int64_t)t * stride) + pad + (int64_t)tt * stride) * c;
+    for (int ch = threadIdx.x * 4; ch < c; ch += 512) {
+        const float4 p = *reinterpret_cast<const float4*>(x + ch), q = *reinterpret_cast<const float4*>(x + c + ch);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias) bv = *reinterpret_cast<const float4*>(bias + ch);
+        for (int r = 0; r < stride; r++) {
+            const float4 a = *reinterpret_cast<const float4*>(w0 + (int64_t)r * c + ch), d = *reinterpret_cast<const float4*>(w1 + (int64_t)r * c + ch);
+            float4 v;
+            v.x = p.x * a.x + q.x * d.x; v.y = p.y * a.y + q.y * d.y; v.z = p.z * a.z + q.z * d.z; v.w = p.w * a.w + q.w * d.w;
+            if (bias) { v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w; }
+            *reinterpret_cast<float4*>(o + (int64_t)r * c + ch) = v;
+        }
+    }
+}
 __global__ void k_upsample_dw(const float* in, const float* w0, const float* w1, const float* bias, int b, int t, int f0, int f1, int c,
                               int stride, float* out, int pad) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -514,6 +568,10 @@ void launch_upsample_depthwise(const float* in, const float* w0, const float* w1
                                int c, int stride, float* out, int out_pad_rows, hipStream_t stream) {
     int64_t tot = (int64_t)b * (f1 - f0) * stride * c;
     if (tot <= 0) return;
+    if (c % 4 == 0 && aligned16(in) && aligned16(w0) && aligned16(w1) && aligned16(out) && (!bias || aligned16(bias)) && (int64_t)b * (f1 - f0) < (1 << 30)) {
+        hipLaunchKernelGGL(k_upsample_dw4, dim3((unsigned)(b * (f1 - f0))), dim3(128), 0, stream, in, w0, w1, bias, t, f0, f1 - f0, c, stride, out, out_pad_rows);
+        return;
+    }
     hipLaunchKernelGGL(k_upsample_dw, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, stream, in, w0, w1, bias, b, t, f0, f1, c, stride, out, out_pad_rows);
 }
 

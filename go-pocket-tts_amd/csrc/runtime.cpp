@@ -1063,6 +1063,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     if ((int64_t)T * d.up_stride > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)T * d.up_stride));
     MimiWs mw;
     mimi_setup(m, mw, B, T);
+    mimi_zero_history(m, mw, m.stream2);   // nine small launches: under the AR loop instead of between the loop and the decoder
     DevBuf& pcm = m.work(7, (size_t)B * T * spf * sizeof(float));
     const char* env_chunk = getenv("PTTS_MIMI_CHUNK");
     int chunk = env_chunk && atoi(env_chunk) > 0 ? atoi(env_chunk) : 1 << 30;   // default: decode after the loop (measured: overlapping

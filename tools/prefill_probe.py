@@ -15,7 +15,7 @@ path = bench.checkpoint_path(pkg, wl["file"], 0, lambda: None)
 model = pkg.Model.open(path, device=0, weights=wl["weights"], kv=wl["kv"], max_batch=64)
 voice = model.upload_voice(pkg.VoiceModelState(bench.voice_modules(pkg, cfg)))
 prompts = [p.tolist() for p in pkg.synth.make_prompts(64, 25, 4000, seed=3)]
-c = pkg.RuntimeGenerateConfig(max_steps=2, eos_threshold=float("inf"), frames_after_eos=3, device_voice=voice)
+c = pkg.RuntimeGenerateConfig(max_steps=int(os.environ.get("PTTS_PROBE_STEPS", "2")), eos_threshold=float("inf"), frames_after_eos=3, device_voice=voice)
 for _ in range(3):
     out = model.generate_batch(prompts, [c] * 64)
 print("frames", out[0].n_frames)
