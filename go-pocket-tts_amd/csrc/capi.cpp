@@ -68,7 +68,7 @@ void ptts_default_opts(ptts_opts* o) {
     o->weights = PTTS_WEIGHTS_F32;
     o->kv = PTTS_KV_F32;
     o->max_batch = 64;
-    o->use_graph = 1;
+    o->use_graph = 0;
 }
 
 const char* ptts_last_error(void) { return last_error_ref().c_str(); }

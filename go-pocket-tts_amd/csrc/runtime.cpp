@@ -1046,7 +1046,9 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             if (reqs[idx[i]].noise) h2d(b.noise.as<float>() + (size_t)i * b.max_steps * ld, reqs[idx[i]].noise, (size_t)ms[i] * ld * sizeof(float), s);
     }
     m.tcomb_for(lsd);
-    const bool use_graph = m.opts.use_graph != 0 && !m.prof.on;
+    // PTTS_GRAPH=0/1 overrides the option (A/B measurement, tools/eager_vs_graph.py)
+    static const int env_graph = [] { const char* e = getenv("PTTS_GRAPH"); return e ? atoi(e) : -1; }();
+    const bool use_graph = (env_graph >= 0 ? env_graph != 0 : m.opts.use_graph != 0) && !m.prof.on;
     if (use_graph) capture_step_graph(b, lsd);
     bool may_stop = false, any_cb = false;
     for (int i = 0; i < B; i++) {

@@ -245,7 +245,7 @@ class ModelInfo:
     frame_rate: float; encoder_frame_rate: float; n_params: int; arena_bytes: int; weights: int; kv: int
 
 
-def _opts(device=0, weights=WEIGHTS_F32, kv=KV_F32, max_batch=64, use_graph=True) -> _Opts:
+def _opts(device=0, weights=WEIGHTS_F32, kv=KV_F32, max_batch=64, use_graph=False) -> _Opts:
     o = _Opts()
     lib().ptts_default_opts(C.byref(o))
     o.device, o.weights, o.kv, o.max_batch, o.use_graph = device, weights, kv, max_batch, 1 if use_graph else 0

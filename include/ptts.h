@@ -55,7 +55,10 @@ typedef struct ptts_opts {
     int32_t weights;         /* PTTS_WEIGHTS_* */
     int32_t kv;              /* PTTS_KV_* */
     int32_t max_batch;       /* utterances stepped together on the GPU (default 64) */
-    int32_t use_graph;       /* 1: the AR step is captured once into a hipGraph and replayed */
+    int32_t use_graph;       /* 0 (default): the ~47 launches of an AR step are issued per step -- the host stays ~3x ahead of
+                                the GPU and there is no gap between steps; 1: the step is captured once into a hipGraph and
+                                replayed (one host call per step, ~8 us of idle GPU between replays: up to 3 % slower, but the
+                                launching thread needs a fraction of the CPU time) */
     int32_t reserved[11];
 } ptts_opts;
 

@@ -218,7 +218,7 @@ def test_generate_matches_oracle_fixed_length(pkg, tiny):
     # GenerateAudio returns the PCM alone
     assert np.array_equal(rt.generate_audio(toks, cfg), got.pcm)
     # graph replay and eager launches are the same computation
-    gm2 = pkg.Model.open(tiny[1], device=0, use_graph=False)
+    gm2 = pkg.Model.open(tiny[1], device=0, use_graph=True)
     got2 = pkg.Runtime(gm2).generate(toks, cfg)
     assert np.array_equal(got2.latents, got.latents) and np.array_equal(got2.pcm, got.pcm)
     gm2.close()
