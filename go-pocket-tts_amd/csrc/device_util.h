@@ -25,6 +25,14 @@ __device__ __forceinline__ float silu1(float v) { return v / (1.0f + expf(-v)); 
 __device__ __forceinline__ float elu_fast(float v) { return v <= 0.0f ? __expf(v) - 1.0f : v; }
 __device__ __forceinline__ float gelu1(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }  // :84-94
 
+// audio.WritePCM16Samples (audio/wav_stream.go:43-54) for one sample
+__device__ __forceinline__ int pcm16_one(float s) {
+    double c = (double)s;                       // the reference clamps and multiplies in float64: the product is exact
+    c = c > 1.0 ? 1.0 : c;
+    c = c < -1.0 ? -1.0 : c;
+    return s != s ? 0 : (int)(c * 32767.0);     // float -> int conversion truncates toward zero, like Go's int16(x)
+}
+
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
     unsigned u = __float_as_uint(f);

@@ -179,10 +179,14 @@ void launch_pcm16_rows(const float* in, int16_t* out, int rows, int64_t row_stri
 
 // One SEANet residual block (+ optionally the final conv) as a single launch, resblock.hip.  u / uo: channels-last
 // [B][pad + L][C] with `pad` zero history rows per utterance; rows [t0, t1) of every utterance are produced.
+// final_conv with rows: utterance b's samples [0, lim) go straight to dst (f32, or int16 through WritePCM16Samples' arithmetic) --
+// dst may be page-locked host memory: the kernel's stores are the device->host transfer
+struct PcmRow { void* dst; int32_t lim; int32_t s16; };
 struct ResArgs {
     const float* u = nullptr; int64_t u_bs = 0; int pad = 0;
     float* uo = nullptr;                       // elu(u + block(u)), same layout as u (not written when final_conv)
     float* pcm = nullptr; int64_t pcm_bs = 0;  // final_conv: [B][L] samples
+    const PcmRow* pcm_rows = nullptr;          // final_conv: if set, used instead of pcm (t0 % 4 == 0, dst 16-byte aligned)
     const void* w1 = nullptr; const void* w1_lo = nullptr; const float* b1 = nullptr;   // conv k1 (3): fragment-ordered [H][3C]
     const void* w2 = nullptr; const void* w2_lo = nullptr; const float* b2 = nullptr;   // conv k2 (1): fragment-ordered [C][H]
     const void* wf_hi = nullptr; const void* wf_lo = nullptr; const float* bf = nullptr;  // final conv as a one-column fragment-ordered matrix (hi + lo planes), bias [1]

@@ -671,12 +671,6 @@ void launch_conv_final(const float* in, int in_pad_rows, const float* w, const f
 // ------------------------------------------------------------------------------------------------
 // PCM egress: audio.WritePCM16Samples on the device -- halves the bytes that cross PCIe
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int pcm16_one(float s) {
-    double c = (double)s;                       // the reference clamps and multiplies in float64: the product is exact
-    c = c > 1.0 ? 1.0 : c;
-    c = c < -1.0 ? -1.0 : c;
-    return s != s ? 0 : (int)(c * 32767.0);     // float -> int conversion truncates toward zero, like Go's int16(x)
-}
 __global__ void k_pcm16(const float* in, int16_t* out, int64_t n) {
     const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
     if (i + 8 <= n) {

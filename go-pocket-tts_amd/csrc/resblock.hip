@@ -215,14 +215,47 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc, 0, 0, 0);
         }
         const int gr = row0 + i_lane;                 // result column 0 sits in register 0 of lane group 0
-        if (g == 0 && i_lane >= HALO && gr < a.t1 && gr < a.L) a.pcm[(int64_t)bi * a.pcm_bs + gr] = acc[0] + (a.bf ? a.bf[0] : 0.0f);
+        const float smp = acc[0] + (a.bf ? a.bf[0] : 0.0f);
+        if (a.pcm_rows) {
+            // the tile's TOUT samples are gathered in LDS (the hidden planes are free by now) and leave as 16-byte (f32) or
+            // 8-byte (int16) pieces per lane, contiguous over the first lanes of the block: sized for a PCIe write
+            float* stage = reinterpret_cast<float*>(h_hi);
+            if (g == 0) stage[i_lane] = smp;
+            __syncthreads();
+            const PcmRow pr = a.pcm_rows[bi];
+            const int lim = min(min(a.t1, a.L), pr.lim);
+            const int j = tid * 4, idx = tb + j;
+            if (j < TOUT && idx < lim) {
+                const float4 v = *reinterpret_cast<const float4*>(stage + HALO + j);
+                if (pr.s16) {
+                    int16_t* dst = reinterpret_cast<int16_t*>(pr.dst) + idx;
+                    const int s0 = pcm16_one(v.x), s1 = pcm16_one(v.y), s2 = pcm16_one(v.z), s3 = pcm16_one(v.w);
+                    if (idx + 3 < lim) *reinterpret_cast<uint2*>(dst) = make_uint2((unsigned)(s0 & 0xffff) | ((unsigned)s1 << 16), (unsigned)(s2 & 0xffff) | ((unsigned)s3 << 16));
+                    else {
+                        dst[0] = (int16_t)s0;
+                        if (idx + 1 < lim) dst[1] = (int16_t)s1;
+                        if (idx + 2 < lim) dst[2] = (int16_t)s2;
+                    }
+                } else {
+                    float* dst = reinterpret_cast<float*>(pr.dst) + idx;
+                    if (idx + 3 < lim) *reinterpret_cast<float4*>(dst) = v;
+                    else {
+                        dst[0] = v.x;
+                        if (idx + 1 < lim) dst[1] = v.y;
+                        if (idx + 2 < lim) dst[2] = v.z;
+                    }
+                }
+            }
+        } else if (g == 0 && i_lane >= HALO && gr < a.t1 && gr < a.L) {
+            a.pcm[(int64_t)bi * a.pcm_bs + gr] = smp;
+        }
     }
 }
 
 bool resblock_supported(const ResArgs& a) {
     const bool dims = (a.C == 64 && a.H == 32) || (a.C == 128 && a.H == 64);
     return dims && a.k1 == 3 && a.k2 == 1 && a.w1 && a.w2 && (a.w_bf16 || (a.w1_lo && a.w2_lo)) && a.pad >= 2 && aligned16(a.u) &&
-           (a.final_conv ? (a.kf == 3 && a.wf_hi && a.wf_lo && a.pcm) : (a.uo != nullptr && aligned16(a.uo))) && a.u_bs % 4 == 0 && a.t1 > a.t0;
+           (a.final_conv ? (a.kf == 3 && a.wf_hi && a.wf_lo && (a.pcm_rows ? a.t0 % 4 == 0 : a.pcm != nullptr)) : (a.uo != nullptr && aligned16(a.uo))) && a.u_bs % 4 == 0 && a.t1 > a.t0;
 }
 
 template <int C, int H, int NW>

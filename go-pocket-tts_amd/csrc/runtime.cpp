@@ -702,7 +702,8 @@ static void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
 // frames [f0, f1) of every utterance; lat: device [B][*][ldim] with lat_bstride elements between utterances;
 // pcm: device [B][T * samples_per_frame]; mimi_latent (optional): [B][C][T] (whole range only)
 void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
-                int final_groups, const std::function<void(int, int)>* after_group) {
+                const PcmRow* pcm_rows, bool* rows_used) {
+    if (rows_used) *rows_used = false;
     const Desc& d = m.d;
     const int B = w.B, T = w.T, C = d.mimi_dim, S = d.up_stride, T1 = T * S, F = d.mimi_ffn, P0 = w.P0;
     if (f1 <= f0) return;
@@ -797,21 +798,18 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
                 ra.final_conv = 1; ra.kf = d.final_k; ra.wf_hi = m.at<uint8_t>(d.final_wf); ra.wf_lo = m.at<uint8_t>(d.final_wf_lo); ra.bf = m.at<float>(d.final_b);
                 ra.pcm = pcm; ra.pcm_bs = w.Ls[3];
             }
-            if (d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 == d.rb2[j].bf16 && resblock_supported(ra)) {
-                if (j == 2 && final_groups > 1 && after_group) {
-                    // the launch that produces the samples runs per group of utterances, so that the caller can start moving
-                    // a group's audio to the host while the next group is computed
-                    const int per = (B + final_groups - 1) / final_groups;
-                    for (int b0 = 0; b0 < B; b0 += per) {
-                        const int b1 = std::min(B, b0 + per);
-                        ResArgs rg = ra;
-                        rg.u = ra.u + (int64_t)b0 * ra.u_bs; rg.pcm = ra.pcm + (int64_t)b0 * ra.pcm_bs; rg.B = b1 - b0;
-                        launch_resblock(rg, s);
-                        (*after_group)(b0, b1);
-                    }
-                } else {
-                    launch_resblock(ra, s);
+            if (j == 2 && pcm_rows && d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 == d.rb2[j].bf16) {
+                ResArgs rr = ra;
+                rr.pcm_rows = pcm_rows;
+                if (resblock_supported(rr)) {
+                    launch_resblock(rr, s);
+                    if (rows_used) *rows_used = true;
+                    final_done = true;
+                    continue;
                 }
+            }
+            if (d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 == d.rb2[j].bf16 && resblock_supported(ra)) {
+                launch_resblock(ra, s);
                 if (j == 2) final_done = true;
                 continue;
             }
@@ -1103,14 +1101,14 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         if (m.events.size() <= ev_used) { hipEvent_t e; PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); m.events.push_back(e); }
         return m.events[ev_used++];
     };
-    int final_groups = 1;
-    const std::function<void(int, int)>* after_group = nullptr;
+    const PcmRow* pcm_rows = nullptr;
+    bool* rows_used = nullptr;
     auto decode_upto = [&](int f1) {
         if (f1 <= f_done) return;
         hipEvent_t e = next_event();
         PTTS_HIP(hipEventRecord(e, s));
         PTTS_HIP(hipStreamWaitEvent(m.stream2, e, 0));
-        mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2, final_groups, after_group);
+        mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2, f_done == 0 ? pcm_rows : nullptr, rows_used);
         f_done = f1;
     };
     auto emit_upto = [&](int f1) {   // hand frames [f_emitted, f1) to the streaming callbacks (they are decoded: f1 <= f_done)
@@ -1185,6 +1183,8 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         bool any_s16 = false;
         for (int i = 0; i < B; i++) any_s16 |= reqs[idx[i]].pcm_format == PTTS_PCM_S16 && !cancelled[i] && !stream_host[(size_t)i];
         if (any_s16) pcm_s16 = &m.work(8, (size_t)B * T * spf * sizeof(int16_t));
+        std::vector<void*> host_dst((size_t)B, nullptr);   // page-locked result buffers allocated ahead of the decoder (direct rows)
+        bool direct_done = false;                          // the decoder's last kernel wrote the samples into host_dst itself
         // results of utterances [b0, b1): buffers, and the copies queued on s
         auto finish_rows = [&](int b0, int b1) {
         for (int i = b0; i < b1; i++) {
@@ -1198,14 +1198,16 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
                 else r.pcm = (float*)stream_host[(size_t)i];
                 stream_host[(size_t)i] = nullptr;
             } else if (reqs[idx[i]].pcm_format == PTTS_PCM_S16) {
-                r.pcm16 = (int16_t*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(int16_t));
+                r.pcm16 = (int16_t*)(host_dst[(size_t)i] ? host_dst[(size_t)i] : result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(int16_t)));
+                host_dst[(size_t)i] = nullptr;
                 if (!r.pcm16) { fail_req(r, PTTS_ENOMEM); continue; }
-                if (r.n_samples > 0)
+                if (r.n_samples > 0 && !direct_done)
                     PTTS_HIP(hipMemcpyAsync(r.pcm16, pcm_s16->as<int16_t>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(int16_t), hipMemcpyDeviceToHost, s));
             } else {
-                r.pcm = (float*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
+                r.pcm = (float*)(host_dst[(size_t)i] ? host_dst[(size_t)i] : result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float)));
+                host_dst[(size_t)i] = nullptr;
                 if (!r.pcm) { fail_req(r, PTTS_ENOMEM); continue; }
-                if (r.n_samples > 0)   // all copies are queued back to back; one wait below
+                if (r.n_samples > 0 && !direct_done)   // all copies are queued back to back; one wait below
                     PTTS_HIP(hipMemcpyAsync(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), hipMemcpyDeviceToHost, s));
             }
             if (reqs[idx[i]].want_latents) {
@@ -1216,32 +1218,37 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             r.status = PTTS_OK;
         }
         };
-        // Whole batch decoded in one go (the default): the launch that writes the samples is cut into groups of utterances and
-        // each group's device->host copies are queued (on s) behind it, so that the PCIe transfer of one group runs under the
-        // kernel of the next; only the last group's copies are exposed.
-        const bool grouped = !streaming && f_done == 0 && B >= 8;
-        int rows_finished = 0;   // stays 0 when the decoder took a path without the grouped launch
-        std::function<void(int, int)> on_group = [&](int b0, int b1) {
-            rows_finished += b1 - b0;
-            if (pcm_s16) launch_pcm16(pcm.as<float>() + (size_t)b0 * T * spf, pcm_s16->as<int16_t>() + (size_t)b0 * T * spf, (int64_t)(b1 - b0) * T * spf, m.stream2);
-            hipEvent_t e = next_event();
-            PTTS_HIP(hipEventRecord(e, m.stream2));
-            PTTS_HIP(hipStreamWaitEvent(s, e, 0));
-            finish_rows(b0, b1);
-        };
-        if (grouped) { final_groups = 4; after_group = &on_group; }
+        // Whole batch decoded in one go (the default): the decoder's last kernel stores every utterance's samples straight into
+        // its page-locked result buffer (f32 or int16) -- the kernel's stores ARE the device->host transfer: no device PCM buffer,
+        // no copies, no copy kernels competing with the decoder.  PTTS_PCM_DIRECT=0: device buffer + copies (A/B measurement).
+        static const bool env_direct = [] { const char* e = getenv("PTTS_PCM_DIRECT"); return !e || atoi(e) != 0; }();
+        const bool try_direct = env_direct && !streaming && f_done == 0;
+        const PcmRow* d_rows = nullptr;
+        if (try_direct) {
+            std::vector<PcmRow> rows((size_t)B, PcmRow{nullptr, 0, 0});
+            for (int i = 0; i < B; i++) {
+                if (cancelled[i]) continue;
+                const bool s16 = reqs[idx[i]].pcm_format == PTTS_PCM_S16;
+                const int64_t ns = (int64_t)nf[i] * spf;
+                host_dst[(size_t)i] = result_alloc((size_t)std::max<int64_t>(1, ns) * (s16 ? sizeof(int16_t) : sizeof(float)));
+                if (!host_dst[(size_t)i]) continue;   // reported as PTTS_ENOMEM by finish_rows
+                rows[(size_t)i] = PcmRow{host_dst[(size_t)i], (int32_t)std::min<int64_t>(ns, INT32_MAX), s16 ? 1 : 0};
+            }
+            DevBuf& rb = m.work(11, rows.size() * sizeof(PcmRow));
+            h2d(rb.p, rows.data(), rows.size() * sizeof(PcmRow), s);
+            d_rows = rb.as<PcmRow>();
+        }
+        pcm_rows = d_rows; rows_used = &direct_done;
         decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
-        final_groups = 1; after_group = nullptr;
+        pcm_rows = nullptr; rows_used = nullptr;
         emit_upto(std::min(steps_run, Tmax));
-        const bool rows_done = rows_finished == B;
         PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int32_t* p : stream_nf) (void)hipHostFree(p);
         stream_nf.clear();
         mark("mimi");
-        if (!rows_done) {
-            if (pcm_s16) launch_pcm16(pcm.as<float>(), pcm_s16->as<int16_t>(), (int64_t)B * T * spf, s);
-            finish_rows(0, B);
-        }
+        if (pcm_s16 && !direct_done) launch_pcm16(pcm.as<float>(), pcm_s16->as<int16_t>(), (int64_t)B * T * spf, s);
+        finish_rows(0, B);
+        for (void* p : host_dst) result_free(p);   // rows that were allocated but not handed out (failed requests)
         PTTS_HIP(hipStreamSynchronize(s));
         mark("results d2h");
     } else {

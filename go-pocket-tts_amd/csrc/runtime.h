@@ -126,10 +126,10 @@ struct MimiWs {
     bool zeroed = false;
 };
 void mimi_setup(Model& m, MimiWs& w, int B, int T);
-// final_groups > 1 with after_group: the launch that writes the samples is issued per group of utterances and
-// after_group(b0, b1) is called (on the host, at enqueue time) behind each, so the caller can queue that group's copies
+// pcm_rows (device array of B PcmRow, whole range only): the fused final block writes every utterance's samples straight to its
+// row (page-locked host memory) instead of pcm; *rows_used says whether that path was taken (false: pcm holds the samples)
 void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
-                int final_groups = 1, const std::function<void(int, int)>* after_group = nullptr);
+                const PcmRow* pcm_rows = nullptr, bool* rows_used = nullptr);
 
 Model* model_open(Plan* plan, void* device_arena, int fill);
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);

@@ -204,6 +204,27 @@ def test_fused_seanet_range_decode_equals_whole(sea64):
     assert np.array_equal(full[:, : 2 * 1920], short)
 
 
+@pytest.mark.parametrize("pcm16", [False, True])
+def test_generate_writes_result_rows_from_the_last_decoder_kernel(pkg, sea64, pcm16):
+    """With the fused final block, GenerateAudio's samples never pass through a device PCM buffer: the kernel stores each
+    utterance's [0, n_samples) straight into its page-locked result (f32, or int16 through WritePCM16Samples' arithmetic).
+    Three utterances of different lengths (row limits, a ragged last tile) against a stand-alone decode of the same latents."""
+    _, om, gm = sea64
+    toks = [[10, 20, 30], [5, 6], [7, 8, 9, 11]]
+    steps = [3, 1, 2]
+    cfgs = [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=n, want_latents=True, pcm16=pcm16) for n in steps]
+    outs = gm.generate_batch(toks, cfgs)
+    lat = np.zeros((3, max(steps), 32), np.float32)     # same batch shape -> same kernels: the comparison is exact; the decoder is
+    for i, (o, n) in enumerate(zip(outs, steps)):       # causal, so what follows an utterance's last frame does not reach its samples
+        lat[i, :n] = o.latents
+    whole = gm.decode_latents(lat)
+    for i, (o, n) in enumerate(zip(outs, steps)):
+        assert o.n_frames == n
+        want = whole[i, : n * 1920]
+        assert o.pcm.shape == (n * 1920,) and o.pcm.dtype == (np.int16 if pcm16 else np.float32)
+        assert np.array_equal(o.pcm, O.pcm16(want) if pcm16 else want)
+
+
 def test_generate_matches_oracle_fixed_length(pkg, tiny):
     _, _, om, gm = tiny
     rt = pkg.Runtime(gm)
