@@ -8,25 +8,48 @@
 namespace ptts {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+union FragW {
+    bf16x8 v;
+    uint4 q;
+    unsigned u[4];
+};
+
+// (a, b) -> packed bf16 hi pair and bf16 lo pair with a = hi + lo to ~2^-17 (round-to-nearest-even)
+__device__ __forceinline__ void split2w(float a, float b, unsigned& hi, unsigned& lo) {
+    f32x2 f = {a, b};
+    bf16x2 h = __builtin_convertvector(f, bf16x2);
+    f32x2 r = f - __builtin_convertvector(h, f32x2);
+    bf16x2 l = __builtin_convertvector(r, bf16x2);
+    hi = *reinterpret_cast<unsigned*>(&h);
+    lo = *reinterpret_cast<unsigned*>(&l);
+}
 
 // One WAVE owns 32 consecutive query rows of one (utterance, head) and walks the union of their windows (at most
-// 32 + context - 1 keys) in tiles of 32 keys with the f32 matrix instruction v_mfma_f32_32x32x2_f32 -- f32 in, f32
-// accumulate, so no precision is given up against the reference's float32 arithmetic.  Everything is computed
-// TRANSPOSED so that no operand ever has to be re-laid-out through LDS:
-//   S^T[key][query] = K * Q^T      A = K tile  (lane&31 = key,  lane>>5 = which half of the 64 head dims),
-//                                  B = Q^T     (lane&31 = query, same half); 32 steps, step s pairs dim s with dim 32+s.
+// 32 + context - 1 keys) in tiles of 32 keys on the matrix cores.  Everything is computed TRANSPOSED so that no operand
+// ever has to be re-laid-out through LDS:
+//   S^T[key][query] = K * Q^T      A = K tile  (lane&31 = key,   lane>>5 = k group),
+//                                  B = Q^T     (lane&31 = query, lane>>5 = k group); v_mfma_f32_32x32x16_bf16, step i covers head
+//                                  dims 16 i .. 16 i + 15, k group g of a step = dims 16 i + 8 g .. + 7 (32 contiguous bytes per lane).
 //   D layout of the 32x32 result:  lane&31 = query, register r = key (r&3) + 8*(r>>2) + 4*(lane>>5)
-//   O^T[dim][query] += V^T * P^T   B at step r is register r of P^T exactly as the first product left it (the two lane
-//                                  halves hold the two keys of the step), A = V^T (lane&31 = dim, lane>>5 = key of the pair).
-// Each lane therefore owns ONE query column: the running maximum, the running sum and the rescale factor of the
-// streaming softmax are per-lane scalars (one cross-half exchange per tile), and the output divides by the sum at
-// the end.  Keys are fetched straight from the qkv rows in HBM/L2 (each K row half is 128 contiguous bytes per lane,
-// each V fetch is two 128-byte row pieces per instruction); a block is 4 waves = 4 neighbouring query tiles so their
-// overlapping windows meet in L1/L2.  Sums are in a fixed order: results are bitwise reproducible.
+//   O^T[dim][query] += V^T * P^T   B of step i = registers 8 i .. 8 i + 7 of P^T exactly as the first product left them (the k
+//                                  index of the second product is DEFINED as that order: k group g, element e of step i = key
+//                                  (r&3) + 8*(r>>2) + 4 g with r = 8 i + e), A = V^T (lane&31 = dim, same keys).
+// Operands are f32 split into bf16 hi + lo halves in registers (x = hi + lo to ~2^-17) and every product is three MFMAs
+// (hi*hi + lo*hi + hi*lo, f32 accumulation): products exact to ~2^-16 relative -- an eighth of the matrix-core time of the f32
+// instruction (v_mfma_f32_32x32x2_f32), which this kernel used first (1090 -> see DESIGN.md).  A bf16 KV cache needs no split
+// (its lo half is zero): two MFMAs per product.
+// Each lane owns ONE query column: the running maximum, the running sum and the rescale factor of the streaming softmax are
+// per-lane scalars (one cross-half exchange per tile), and the output divides by the sum at the end.  Keys are fetched
+// straight from the qkv rows in HBM/L2; a block is 4 waves = 4 neighbouring query tiles so their overlapping windows meet in
+// L1/L2.  Sums are in a fixed order: results are bitwise reproducible.
 //
 // The same kernel serves the prompt prefill of the FlowLM transformer (flow_transformer.go:749-771; RAGGED): the queries of
 // segment s are the packed rows [rag_off[s], rag_off[s+1]) at positions rag_pos0[s] + i, the keys are the segment's cache rows
-// 0 .. position (context < 0: no window), stored as f32 or bf16 (KVBF16: widened on load, f32 arithmetic as above).
+// 0 .. position (context < 0: no window), stored as f32 or bf16 (KVBF16).
 template <bool KVBF16, bool RAGGED>
 __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -48,13 +71,16 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     const RowMap qm{a.q_ld, a.q_rows_per_batch, a.q_batch_stride}, om{a.out_ld, a.o_rows_per_batch, a.o_batch_stride};
     const int row = seg_row0 + r0 + my_q;
 
-    float q[32];
+    FragW qh[4], ql[4];   // step i: dims 16 i + 8 half .. + 7 of the lane's query, scaled by 1/sqrt(64) (exact)
     {
-        const float* qp = a.q + row_off(qm, row) + a.q_col0 + h * 64 + half * 32;
+        const float* qp = a.q + row_off(qm, row) + a.q_col0 + h * 64 + half * 8;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const float4 t = *reinterpret_cast<const float4*>(qp + i * 4);
-            q[4 * i] = t.x * 0.125f; q[4 * i + 1] = t.y * 0.125f; q[4 * i + 2] = t.z * 0.125f; q[4 * i + 3] = t.w * 0.125f;   // 1/sqrt(64), exact
+        for (int i = 0; i < 4; i++) {
+            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * i), t1 = *reinterpret_cast<const float4*>(qp + 16 * i + 4);
+            split2w(t0.x * 0.125f, t0.y * 0.125f, qh[i].u[0], ql[i].u[0]);
+            split2w(t0.z * 0.125f, t0.w * 0.125f, qh[i].u[1], ql[i].u[1]);
+            split2w(t1.x * 0.125f, t1.y * 0.125f, qh[i].u[2], ql[i].u[2]);
+            split2w(t1.z * 0.125f, t1.w * 0.125f, qh[i].u[3], ql[i].u[3]);
         }
     }
     typedef typename std::conditional<KVBF16, unsigned short, float>::type KvT;
@@ -66,26 +92,29 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     float m = -INFINITY, l = 0.0f;
 
     for (int kt = j_lo; kt <= p_last; kt += 32) {
-        float kr[32];
+        FragW kh[4], kl[4];
         {
-            const KvT* kp = kb + (int64_t)min(kt + j, p_last) * a.k_row_stride + half * 32;
+            const KvT* kp = kb + (int64_t)min(kt + j, p_last) * a.k_row_stride + half * 8;
             if constexpr (KVBF16) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const uint4 t = *reinterpret_cast<const uint4*>(kp + i * 8);   // 8 bf16: element e is the low half of word e/2 for even e
-                    kr[8 * i] = __uint_as_float(t.x << 16); kr[8 * i + 1] = __uint_as_float(t.x & 0xffff0000u);
-                    kr[8 * i + 2] = __uint_as_float(t.y << 16); kr[8 * i + 3] = __uint_as_float(t.y & 0xffff0000u);
-                    kr[8 * i + 4] = __uint_as_float(t.z << 16); kr[8 * i + 5] = __uint_as_float(t.z & 0xffff0000u);
-                    kr[8 * i + 6] = __uint_as_float(t.w << 16); kr[8 * i + 7] = __uint_as_float(t.w & 0xffff0000u);
-                }
+                for (int i = 0; i < 4; i++) kh[i].q = *reinterpret_cast<const uint4*>(kp + 16 * i);   // 8 bf16 = one operand, as stored
             } else {
+                float4 t[4][2];
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float4 t = *reinterpret_cast<const float4*>(kp + i * 4);
-                    kr[4 * i] = t.x; kr[4 * i + 1] = t.y; kr[4 * i + 2] = t.z; kr[4 * i + 3] = t.w;
+                for (int i = 0; i < 4; i++) {
+                    t[i][0] = *reinterpret_cast<const float4*>(kp + 16 * i);
+                    t[i][1] = *reinterpret_cast<const float4*>(kp + 16 * i + 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    split2w(t[i][0].x, t[i][0].y, kh[i].u[0], kl[i].u[0]);
+                    split2w(t[i][0].z, t[i][0].w, kh[i].u[1], kl[i].u[1]);
+                    split2w(t[i][1].x, t[i][1].y, kh[i].u[2], kl[i].u[2]);
+                    split2w(t[i][1].z, t[i][1].w, kh[i].u[3], kl[i].u[3]);
                 }
             }
         }
+        // values of the tile's 32 keys for dims j and 32 + j, in the key order of the score registers
         float v0[16], v1[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -103,7 +132,11 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 32; i++) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kr[i], q[i], s, 0, 0, 0);
+        for (int i = 0; i < 4; i++) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[i].v, qh[i].v, s, 0, 0, 0);
+            if constexpr (!KVBF16) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[i].v, qh[i].v, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[i].v, ql[i].v, s, 0, 0, 0);
+        }
         float tmax = -INFINITY;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
@@ -126,9 +159,20 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
             l += s[r];
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0[r], s[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1[r], s[r], o1, 0, 0, 0);
+        for (int i = 0; i < 2; i++) {
+            FragW ph, pl, vh0, vl0, vh1, vl1;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                split2w(s[8 * i + 2 * e], s[8 * i + 2 * e + 1], ph.u[e], pl.u[e]);
+                split2w(v0[8 * i + 2 * e], v0[8 * i + 2 * e + 1], vh0.u[e], vl0.u[e]);
+                split2w(v1[8 * i + 2 * e], v1[8 * i + 2 * e + 1], vh1.u[e], vl1.u[e]);
+            }
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, ph.v, o0, 0, 0, 0);
+            if constexpr (!KVBF16) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0.v, ph.v, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, pl.v, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, ph.v, o1, 0, 0, 0);
+            if constexpr (!KVBF16) o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1.v, ph.v, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, pl.v, o1, 0, 0, 0);
         }
     }
     l += __shfl_xor(l, 32, WAVE);
