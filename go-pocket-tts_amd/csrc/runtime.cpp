@@ -152,6 +152,7 @@ const float* Model::tcomb_for(int n) {
 Batch::~Batch() {
     if (graph) (void)hipGraphExecDestroy(graph);
     if (n_active_pinned) (void)hipHostFree(n_active_pinned);
+    if (rows_pinned) (void)hipHostFree(rows_pinned);
 }
 
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
@@ -192,7 +193,8 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     b->cur.ensure(B * d.ldim * f);
     b->partial.ensure((size_t)16 * B * std::max(d.d_model, d.flow_dim) * f);
     b->latents.ensure(B * b->max_steps * d.ldim * f);
-    PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t), hipHostMallocDefault));
+    PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(1 + 2 * B), hipHostMallocDefault));
+    PTTS_HIP(hipHostMalloc((void**)&b->rows_pinned, sizeof(PcmRow) * std::max<size_t>((size_t)B, 1), hipHostMallocDefault));
     batch_reset(*b);
     return b.release();
 }
@@ -1173,9 +1175,10 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         }
     }
     mark("ar loop");
-    std::vector<int32_t> nf((size_t)B), es((size_t)B);
-    d2h(nf.data(), b.st.n_frames, (size_t)B * 4, s);
-    d2h(es.data(), b.st.eos_step, (size_t)B * 4, s);
+    // n_frames and eos_step sit side by side in the state block: one copy into page-locked memory, one wait
+    PTTS_HIP(hipMemcpyAsync(b.n_active_pinned + 1, b.st.n_frames, (size_t)2 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    PTTS_HIP(hipStreamSynchronize(s));
+    const std::vector<int32_t> nf(b.n_active_pinned + 1, b.n_active_pinned + 1 + B), es(b.n_active_pinned + 1 + B, b.n_active_pinned + 1 + 2 * B);
     int Tmax = 0;
     for (int i = 0; i < B; i++) if (!cancelled[i]) Tmax = std::max(Tmax, nf[i]);
     if (Tmax > 0) {
@@ -1225,17 +1228,18 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         const bool try_direct = env_direct && !streaming && f_done == 0;
         const PcmRow* d_rows = nullptr;
         if (try_direct) {
-            std::vector<PcmRow> rows((size_t)B, PcmRow{nullptr, 0, 0});
+            PcmRow* rows = b.rows_pinned;
+            for (int i = 0; i < B; i++) rows[i] = PcmRow{nullptr, 0, 0};
             for (int i = 0; i < B; i++) {
                 if (cancelled[i]) continue;
                 const bool s16 = reqs[idx[i]].pcm_format == PTTS_PCM_S16;
                 const int64_t ns = (int64_t)nf[i] * spf;
                 host_dst[(size_t)i] = result_alloc((size_t)std::max<int64_t>(1, ns) * (s16 ? sizeof(int16_t) : sizeof(float)));
                 if (!host_dst[(size_t)i]) continue;   // reported as PTTS_ENOMEM by finish_rows
-                rows[(size_t)i] = PcmRow{host_dst[(size_t)i], (int32_t)std::min<int64_t>(ns, INT32_MAX), s16 ? 1 : 0};
+                rows[i] = PcmRow{host_dst[(size_t)i], (int32_t)std::min<int64_t>(ns, INT32_MAX), s16 ? 1 : 0};
             }
-            DevBuf& rb = m.work(11, rows.size() * sizeof(PcmRow));
-            h2d(rb.p, rows.data(), rows.size() * sizeof(PcmRow), s);
+            DevBuf& rb = m.work(11, (size_t)B * sizeof(PcmRow));
+            PTTS_HIP(hipMemcpyAsync(rb.p, rows, (size_t)B * sizeof(PcmRow), hipMemcpyHostToDevice, s));   // page-locked source: no wait needed
             d_rows = rb.as<PcmRow>();
         }
         pcm_rows = d_rows; rows_used = &direct_done;

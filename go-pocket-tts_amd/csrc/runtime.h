@@ -93,7 +93,10 @@ struct Batch {
     hipGraphExec_t graph = nullptr;
     int graph_lsd = 0;
     bool graph_noise = false;
+    // page-locked scratch of the generate loop: [0] live-utterance count, [1, 1+B) n_frames, [1+B, 1+2B) eos_step read back in
+    // one copy after the loop; rows_pinned: the B result rows uploaded to the decoder (no pageable staging, no extra sync)
     int32_t* n_active_pinned = nullptr;
+    PcmRow* rows_pinned = nullptr;
 
     ~Batch();
     size_t kv_elem() const { return m->opts.kv == PTTS_KV_BF16 ? 2 : 4; }
