@@ -33,8 +33,33 @@ static LnArgs mkln(const Model& m, const float* x, RowMap xm, const Norm& n, flo
     return a;
 }
 
+// Small host->device uploads (slot tables, token ids, per-utterance limits): a copy from pageable memory has to be waited for
+// (~20 us each, a dozen per call).  Inside generate_chunk they are staged through a page-locked arena instead and queued
+// without a wait; the arena is rewound when the call starts (the previous call ended with the stream drained).
+static thread_local UploadArena* tl_upload = nullptr;
+namespace {
+struct UploadScope {   // generate_chunk: uploads of this thread go through m.upload until the scope ends
+    UploadScope(UploadArena& a, hipStream_t s) {
+        (void)hipStreamSynchronize(s);   // normally idle already; after a failed call it may still be reading the arena
+        if (!a.base && hipHostMalloc((void**)&a.base, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) a.cap = (size_t)1 << 20;
+        else if (!a.base) (void)hipGetLastError();
+        a.off = 0;
+        tl_upload = &a;
+    }
+    ~UploadScope() { tl_upload = nullptr; }
+};
+}  // namespace
 static void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
+    UploadArena* a = tl_upload;
+    const size_t need = (bytes + 63) & ~(size_t)63;
+    if (a && a->base && a->off + need <= a->cap) {
+        char* stage = a->base + a->off;
+        a->off += need;
+        std::memcpy(stage, src, bytes);
+        PTTS_HIP(hipMemcpyAsync(dst, stage, bytes, hipMemcpyHostToDevice, s));
+        return;
+    }
     PTTS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
     PTTS_HIP(hipStreamSynchronize(s));
 }
@@ -48,6 +73,7 @@ static void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
 // Model
 // ------------------------------------------------------------------------------------------------
 Model::~Model() {
+    if (upload.base) (void)hipHostFree(upload.base);
     for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (stream2) (void)hipStreamDestroy(stream2);
@@ -952,6 +978,7 @@ static void fail_req(ptts_result& r, int code) {
 static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector<int>& idx, ptts_result* res, int lsd) {
     const Desc& d = m.d;
     hipStream_t s = m.stream;
+    UploadScope upload_scope(m.upload, s);
     // PTTS_TRACE=1: host wall time of the phases of one call (stderr); each mark drains the stream first
     static const bool trace = getenv("PTTS_TRACE") != nullptr;
     auto t_last = std::chrono::steady_clock::now();

@@ -41,6 +41,12 @@ struct Prof {   // bench.py measurement hook (ptts_profile_*)
     int64_t launches = 0;
 };
 
+// page-locked staging for the small host->device uploads of one generate call (runtime.cpp: h2d)
+struct UploadArena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0;
+};
+
 struct Model {
     Desc d;
     ptts_opts opts;
@@ -58,6 +64,7 @@ struct Model {
 
     ~Model();
     template <class T> const T* at(size_t off) const { return off == NONE ? nullptr : reinterpret_cast<const T*>(arena + off); }
+    UploadArena upload;
     DevBuf& work(size_t i, size_t bytes) {
         while (ws.size() <= i) ws.emplace_back(new DevBuf());
         ws[i]->ensure(bytes);
