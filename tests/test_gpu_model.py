@@ -542,6 +542,38 @@ def test_split_k_linear2_in_step_and_prefill(pkg, tmp_path, weights):
     om.close()
 
 
+@pytest.mark.parametrize("weights", ["F32", "BF16"])
+def test_prefill_many_rows_split_k_gemm_and_rope_epilogue(pkg, tmp_path, weights):
+    """8 prompts of 60..74 rows = 536 rows (>= 512) at ffn = 2048: the prefill's qkv projection rotates q and k in the GEMM
+    epilogue from per-row positions, linear2 runs as a split-K launch of the tile GEMM whose planes the next LayerNorm adds,
+    attention runs on ragged segments -- every key/value left in the cache against the oracle's, prompt by prompt."""
+    import dataclasses
+    synth = pkg.synth
+    cfg = dataclasses.replace(synth.SynthConfig.tiny(), ffn=2048)
+    path = str(tmp_path / f"ffn2048_rows_{weights}.safetensors")
+    synth.write_safetensors(path, synth.make_checkpoint(cfg, seed=98), dtype=weights)
+    om = O.OracleModel.from_file(path)
+    gm = pkg.Model.open(path, device=0, weights=1 if weights == "BF16" else 0)
+    rng = np.random.default_rng(11)
+    lens = [60, 62, 64, 66, 68, 70, 72, 74]
+    assert sum(lens) >= 512
+    embs = [om.text_embeddings(rng.integers(0, cfg.n_bins, n)) for n in lens]
+    b = gm.new_batch(len(lens), 96)
+    b.prompt(embs)
+    assert list(b.offsets()) == lens
+    for slot in (0, 3, 7):
+        st = om.new_state()
+        om.prompt(st, embs[slot])
+        for layer in range(om.n_layers):
+            ko, vo = st.kv(layer)
+            kg, vg = b.read_kv(slot, layer)
+            parity(f"slot {slot} K layer {layer}", kg, ko, FLOW_TOL)
+            parity(f"slot {slot} V layer {layer}", vg, vo, FLOW_TOL)
+    b.close()
+    gm.close()
+    om.close()
+
+
 def test_mimi_decode_many_rows_takes_the_big_gemm_path(tiny):
     """2 x 20 frames = 640 decoder-transformer rows (>= 512): the direct-to-register GEMM with RoPE in its epilogue, the
     window attention across two utterances of a batch and the range decode all at once, against the oracle."""
