@@ -184,6 +184,7 @@ def main():
     ap.add_argument("--workload", default="b64_10s_bf16", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true")
+    ap.add_argument("--no-two-engines", action="store_true", help="skip the two-engine extra (profiling: its concurrent kernels stretch each other)")
     ap.add_argument("--cpu-frames", type=int, default=63)
     args = ap.parse_args()
 
@@ -236,7 +237,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"[bench] roofline pass failed: {e}")
             result["roofline"] = None
-    if rank == 0 and world == 1 and not args.no_b1 and args.workload == "b64_10s_bf16":
+    if rank == 0 and world == 1 and not args.no_b1 and not args.no_two_engines and args.workload == "b64_10s_bf16":
         # serving configuration, reported beside the headline (not `value`): two engines over the same weights, each running
         # the same 64-utterance passes back to back, so that one pass's Mimi decode overlaps the other's prefill + AR loop
         try:
