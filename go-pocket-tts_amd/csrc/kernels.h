@@ -64,6 +64,7 @@ extern thread_local int g_gemm3_cfg;
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.
 // The optional prologue (SkinnyFuse; needs K == row width <= 1024, splitk == 1) folds the preceding residual update
 // and LayerNorm into the activation staging.
+struct StepFinish;   // defined with StepState below
 struct SkinnyFuse {
     // x[row] += pgate[row] * (sum_z partial[z][row] + pbias)   (partial: [psplit][M][K])
     const float* partial = nullptr; int psplit = 0; int64_t pstride = 0;
@@ -73,6 +74,10 @@ struct SkinnyFuse {
     const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
     const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;   // adaLN modulation
     float* y_out = nullptr;          // the normalised rows, written once (dense [M, K])
+    // last launch of an AR step (the Euler update that produces the frame): the step's bookkeeping (k_step_finish) rides in the
+    // epilogue -- the frame is appended to the utterance's latents and the slot's counters advance.  One column block only
+    // (N <= 64), so every reader of the counters in this launch has read them before the one lane per row that writes them.
+    const StepFinish* fin = nullptr; // device memory
 };
 bool skinny_supported(const GemmArgs& a, int splitk);
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
@@ -210,6 +215,13 @@ struct StepState {
     float*   eos_threshold; // [B]
     int32_t* n_active;      // [1]
     int32_t* broke;         // [B] 1 when the loop left through the countdown `break` (no StepCallback for that step)
+};
+struct StepFinish {         // arguments of k_step_finish, resident in device memory (Batch::fin_dev)
+    StepState s;
+    const float* eos_logit; // [B]
+    float* latents;         // [B][lat_stride]
+    int64_t lat_stride;
+    int32_t ldim;
 };
 // prepares the step input: in32[b] = step==0 ? bos : latents[b][step-1] with NaN -> bos, x0[b] = noise of the step (or 0);
 // with `lin` also x = input_linear(in32) and fx = input_proj(x0) (the two ldim-wide linears of the step, exact f32)

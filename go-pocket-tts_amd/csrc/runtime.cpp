@@ -219,6 +219,11 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     b->cur.ensure(B * d.ldim * f);
     b->partial.ensure((size_t)16 * B * std::max(d.d_model, d.flow_dim) * f);
     b->latents.ensure(B * b->max_steps * d.ldim * f);
+    {
+        StepFinish sf{b->st, b->eos.as<float>(), b->latents.as<float>(), (int64_t)b->max_steps * d.ldim, (int32_t)d.ldim};
+        b->fin_dev.ensure(sizeof sf);
+        h2d(b->fin_dev.p, &sf, sizeof sf, m.stream);
+    }
     PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(1 + 2 * B), hipHostMallocDefault));
     PTTS_HIP(hipHostMalloc((void**)&b->rows_pinned, sizeof(PcmRow) * std::max<size_t>((size_t)B, 1), hipHostMallocDefault));
     batch_reset(*b);
@@ -493,9 +498,11 @@ struct FusedIn {
     const Norm* norm = nullptr; bool affine = true; float eps = 1e-5f;
     const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;
     float* y_out = nullptr;
+    const StepFinish* finish = nullptr;   // the step's last launch: bookkeeping in the epilogue (SkinnyFuse::fin)
 };
 
-static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const Lin& l, float* C, int64_t ldc, int M, int epi,
+// returns whether in.finish was honoured (false: the caller launches k_step_finish itself)
+static bool step_fused_linear(Batch& b, const float* x, const FusedIn& in, const Lin& l, float* C, int64_t ldc, int M, int epi,
                               const float* addvec, const float* R, float alpha, hipStream_t st = nullptr) {
     Model& m = *b.m;
     GemmArgs g = mk(m, x, flat(l.in), l, C, flat(ldc), M);
@@ -507,7 +514,10 @@ static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const
     if (in.norm && in.affine) { fu.ln_w = m.at<float>(in.norm->w); fu.ln_b = m.at<float>(in.norm->b); }
     fu.shift = in.shift; fu.scale = in.scale; fu.ldmod = in.ldmod;
     fu.y_out = in.y_out;
-    if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); return; }
+    fu.fin = in.finish;
+    if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); return fu.fin != nullptr; }
+    fu.fin = nullptr;
+    if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); return false; }
     if (st && st != m.stream) throw Error(PTTS_EINVAL, "ptts-hip: internal: unfused step linear on a side stream");
     // shapes outside the fused kernel (never the reference checkpoint): separate LayerNorm launch, then the linear
     LnArgs ln;
@@ -524,6 +534,7 @@ static void step_fused_linear(Batch& b, const float* x, const FusedIn& in, const
     GemmArgs g2 = mk(m, y, flat(l.in), l, C, flat(ldc), M);
     g2.epi = epi; g2.addvec = addvec; g2.R = R; g2.alpha = alpha;
     step_gemm(m, g2);
+    return false;
 }
 
 // FlowLM.SampleNextLatentStateful minus the host glue (flow_lm.go:252-288): input_linear, 6 x forwardWithState(Tq=1),
@@ -549,7 +560,8 @@ void step_open(Batch& b) {
                       b.in32.as<float>(), b.cur.as<float>(), ok ? &lin : nullptr, m.stream);
 }
 
-void step_core(Batch& b, int lsd, bool opened) {
+bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
+    bool finished = false;
     Model& m = *b.m;
     const Desc& d = m.d;
     hipStream_t s = m.stream;
@@ -669,8 +681,10 @@ void step_core(Batch& b, int lsd, bool opened) {
         FusedIn fin;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
         fin.affine = false; fin.eps = 1e-6f;
         fin.shift = ada + (size_t)d.flow_depth * 3 * C; fin.scale = fin.shift + C; fin.ldmod = NA;
-        step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd);  // current += flow / steps
+        if (fuse_finish && i == lsd - 1) fin.finish = b.fin_dev.as<StepFinish>();
+        finished = step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd);  // current += flow / steps
     }
+    return finished;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -948,8 +962,8 @@ static void capture_step_graph(Batch& b, int lsd) {
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
     step_open(b);
-    step_core(b, lsd, b.opened);
-    launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    if (!step_core(b, lsd, b.opened, true))
+        launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
     PTTS_HIP(hipStreamEndCapture(m.stream, &g));
     hipError_t e = hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -967,8 +981,9 @@ static void enqueue_step(Batch& b, int lsd, bool use_graph) {
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
     step_open(b);
-    step_core(b, lsd, b.opened);
-    launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    static const bool fuse = [] { const char* e = getenv("PTTS_FUSE_FINISH"); return !e || atoi(e) != 0; }();   // A/B measurement
+    if (!step_core(b, lsd, b.opened, fuse))   // the bookkeeping normally rides in the step's last launch
+        launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
 }
 
 static void fail_req(ptts_result& r, int code) {

@@ -104,6 +104,7 @@ struct Batch {
     // one copy after the loop; rows_pinned: the B result rows uploaded to the decoder (no pageable staging, no extra sync)
     int32_t* n_active_pinned = nullptr;
     PcmRow* rows_pinned = nullptr;
+    DevBuf fin_dev;          // StepFinish: what the step's last launch needs for the bookkeeping it carries
 
     ~Batch();
     size_t kv_elem() const { return m->opts.kv == PTTS_KV_BF16 ? 2 : 4; }
@@ -148,7 +149,9 @@ void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64
 // rows: device [R, d_model]; row_offsets host [B+1]
 void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 // core of one AR step on device state: in32 [B, ldim], cur [B, ldim] (= x0) -> cur (= frame), eos, last; appends KV at kv_len
-void step_core(Batch& b, int lsd_steps, bool opened = false);   // opened: x and fx were produced by step_open
+// opened: x and fx were produced by step_open; fuse_finish: the bookkeeping of k_step_finish rides in the last launch -- returns
+// whether it did (false: the caller launches k_step_finish)
+bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = false);
 void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev);
 Model* model_share(Model& base);   // another engine over base's weight arena (base must outlive it)

@@ -60,7 +60,9 @@ constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8;
 // NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024).
 // CG: 16-column groups per block (4: 64 columns x 4 K parts; 1: 16 columns x 16 K parts -- four times the blocks, for
 // launches whose 64-column grid would leave most of the chip idle: batch <= 16, the reference's own batch-1 case)
-template <bool WBF16, bool STAMP, int PRO, int NJ, int CG>
+// FIN: the launch carries the AR step's bookkeeping (SkinnyFuse::fin) -- a template parameter so that the other variants do
+// not hold its eight registers (the fused-prologue variants sit at the 128-register limit of a 16-wave block)
+template <bool WBF16, bool STAMP, int PRO, int NJ, int CG, bool FIN = false>
 __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_m, int p_n, int p_k, int splitk, GemmArgs a, SkinnyFuse fu,
                                                  float* partial, unsigned long long* stamps) {
     // The seven leading scalars (copies of a.Wt, a.A, a.amap.ld, a.M, a.N, a.K, and the split) are what the weight and
@@ -126,6 +128,28 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             for (int reg = 0; reg < 4; reg++) e_g[reg] = a.gate[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.ldg + nc];
         }
     }
+    // fused step bookkeeping: every storing wave reads its rows' counters now; the single lane per row that advances them does
+    // so after the block's last barrier, by which time these reads have returned (forced below)
+    int f_act[FIN ? 4 : 1] = {0}, f_step[FIN ? 4 : 1] = {0};
+    int f_cd[FIN ? 4 : 1] = {0}, f_fae[FIN ? 4 : 1] = {0}, f_max[FIN ? 4 : 1] = {0}, f_kv[FIN ? 4 : 1] = {0};   // the bookkeeping lane's operands,
+    float f_logit[FIN ? 4 : 1] = {0.f}, f_thr[FIN ? 4 : 1] = {0.f};                                             // requested now, used at the very end
+    if constexpr (FIN) {
+        if (kq4 == 0 && splitk <= 1) {
+            const StepState& fs = fu.fin->s;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int mm = min(m0 + q * 4 + reg, p_m - 1);
+                f_act[reg] = fs.active[mm];
+                f_step[reg] = fs.step[mm];
+                f_cd[reg] = fs.countdown[mm];
+                f_fae[reg] = fs.frames_after_eos[mm];
+                f_max[reg] = fs.max_steps[mm];
+                f_kv[reg] = fs.kv_len[mm];
+                f_logit[reg] = fu.fin->eos_logit[mm];
+                f_thr[reg] = fs.eos_threshold[mm];
+            }
+        }
+    }
     __builtin_amdgcn_sched_barrier(0);
     SK_STAMP(1);
     // ---- activations: wave w stages row w of the tile; lane owns float4 columns lane + 64 j ----
@@ -155,7 +179,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         asm volatile("" ::"s"(a.A), "s"(a.amap.ld), "s"(a.W), "s"(a.ldw), "s"(a.Wt), "s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R),
                      "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.tail), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
         asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.pgate), "s"(fu.ldpg), "s"(fu.x_out), "s"(fu.ln),
-                     "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out));
+                     "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out), "s"(fu.fin));
         float4 lw[(PRO & PRO_AFFINE) ? NJ : 1], lb[(PRO & PRO_AFFINE) ? NJ : 1], lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
         auto load_params = [&]() {
             if constexpr ((PRO & PRO_AFFINE) != 0) {
@@ -304,6 +328,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     float4* red = reinterpret_cast<float4*>(Xh);   // [kq4][cg][lane]
     const f32x4 accv = acc_h + acc_l;
     if (kq4 > 0) red[(kq4 * CG + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
+    if constexpr (FIN) asm volatile("" ::"v"(f_act[0]), "v"(f_act[1]), "v"(f_act[2]), "v"(f_act[3]), "v"(f_step[0]), "v"(f_step[1]), "v"(f_step[2]), "v"(f_step[3]));
     __syncthreads();
     SK_STAMP(5);
     if (kq4 > 0 || !n_ok) return;
@@ -341,6 +366,32 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             case EPI_RESADD_ELU: v = elu1(e_r[reg] + v); break;
         }
         a.C[co] = v;
+        if constexpr (FIN)
+            if (f_act[reg]) fu.fin->latents[(int64_t)m * fu.fin->lat_stride + (int64_t)f_step[reg] * fu.fin->ldim + n] = v;   // latentFrames = append(...)
+    }
+    if constexpr (FIN)
+    if (cg == 0 && (lane & 15) == 0) {   // k_step_finish's bookkeeping (runtime_native_safetensors.go:176-192), one lane per row
+        const StepState& fs = fu.fin->s;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int m = m0 + q * 4 + reg;
+            if (m >= p_m || !f_act[reg]) continue;
+            const int st = f_step[reg];
+            const bool is_eos = f_logit[reg] > f_thr[reg];   // flow_lm.go:281
+            int cd = f_cd[reg];
+            bool done = false;
+            if (is_eos && cd < 0) { cd = f_fae[reg]; fs.eos_step[m] = st; }
+            if (cd >= 0) {
+                if (cd == 0) { done = true; fs.broke[m] = 1; }
+                else cd--;
+            }
+            fs.countdown[m] = cd;
+            fs.n_frames[m] = st + 1;
+            fs.step[m] = st + 1;
+            fs.kv_len[m] = f_kv[reg] + 1;
+            if (st + 1 >= f_max[reg]) done = true;
+            if (done) { fs.active[m] = 0; atomicSub(fs.n_active, 1); }
+        }
     }
     if (STAMP) { __builtin_amdgcn_s_waitcnt(0); SK_STAMP(6); }
 #undef SK_STAMP
@@ -356,7 +407,8 @@ bool skinny_supported(const GemmArgs& a, int splitk) {
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
     // the fused prologue needs whole rows in one block: K is the row width, one K slice, dense rows
     return skinny_supported(a, 1) && a.K <= SK_KMAX && a.amap.ld == a.K && a.K % 4 == 0 && (!f.scale || f.ldmod % 4 == 0) &&
-           !f.pgate && (!f.ln_w == !f.ln_b) && (!f.partial || f.psplit >= 1) && (f.ln || !(f.ln_w || f.scale));
+           !f.pgate && (!f.ln_w == !f.ln_b) && (!f.partial || f.psplit >= 1) && (f.ln || !(f.ln_w || f.scale)) &&
+           (!f.fin || (a.N <= 64 && a.K <= 512 && f.ln && f.scale && !f.ln_w && !f.partial));   // fin: instantiated for the flow net's final layer only
 }
 
 thread_local hipEvent_t g_skinny_ev[2] = {nullptr, nullptr};   // measurement pass (bench.py roofline): the kernel's own begin / end timestamps
@@ -365,6 +417,16 @@ thread_local unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_deb
 template <bool WBF16, int PRO, int NJ, int CG>
 static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
     dim3 grid((a.N + 16 * CG - 1) / (16 * CG), (a.M + 15) / 16, splitk);
+    if constexpr (PRO == (PRO_LN | PRO_MOD) && NJ == 2 && CG == 4) {
+        if (fu.fin) {   // the flow net's final layer with the step's bookkeeping in its epilogue (one column block: grid.x == 1)
+            if (g_skinny_ev[0])
+                hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld,
+                                      a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
+            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial,
+                                    (unsigned long long*)nullptr);
+            return;
+        }
+    }
     if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, g_skinny_stamps);
     else if (g_skinny_ev[0])   // hipExtLaunchKernel stamps the dispatch itself: the same interval rocprofv3 reports for the kernel
         hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld, a.M, a.N,
@@ -376,7 +438,7 @@ template <bool WBF16, int PRO, int NJ>
 static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 /*grid*/, hipStream_t stream) {
     // narrow blocks when the 64-column grid would occupy fewer than half of the 256 CUs
     const int blocks64 = ((a.N + 63) / 64) * ((a.M + 15) / 16) * splitk;
-    if (blocks64 < 128 && a.N > 16) launch_cg<WBF16, PRO, NJ, 1>(a, fu, splitk, partial, stream);
+    if (blocks64 < 128 && a.N > 16 && !fu.fin) launch_cg<WBF16, PRO, NJ, 1>(a, fu, splitk, partial, stream);   // fin: one column block (see SkinnyFuse)
     else launch_cg<WBF16, PRO, NJ, 4>(a, fu, splitk, partial, stream);
 }
 
