@@ -1,4 +1,6 @@
 // attn_step.hip -- single-token attention of the AR step (K5 + K6 + K7 in one launch).
+#include <algorithm>
+
 #include "kernels.h"
 #include "device_util.h"
 
@@ -22,6 +24,9 @@ namespace ptts {
 // set cannot occur (the key at the offset always exists).  Keys j < pre_len come from a shared prefix (a device voice)
 // when there is one: identical for every utterance of that voice, so the batch reads one L2-resident copy.
 // Handles up to ATT_NI * 4 * (keys per instruction) keys = 512 (bf16) / 256 (f32); longer caches use k_attention.
+// NI (template): wave-instructions per operand actually issued -- the host knows an upper bound on the cache length of the
+// launch (AttnArgs::keys_now: lengths after the prefill + steps taken), so a step at 200 keys issues 8 + 8 loads per wave
+// and the arithmetic for them instead of the 16 + 16 a 512-key cache would need (slots past the end cost a load each).
 constexpr int ATT_NI = 16;
 
 // address-space-qualified views: a pointer that arrives through memory is 'generic' to the compiler, which then emits
@@ -35,7 +40,7 @@ __device__ __forceinline__ uint4 gload16(const char* p) {
 }
 template <class T> using cptr = const __attribute__((address_space(4))) T*;
 
-template <bool KVBF16>
+template <bool KVBF16, int NI>
 __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
     constexpr int LPK = KVBF16 ? 8 : 16;       // lanes per key (16 B each)
     constexpr int KPI = 64 / LPK;              // keys per wave-instruction
@@ -79,10 +84,10 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
     const float vv = qr[2 * a.d_model + e64];
     __builtin_amdgcn_sched_barrier(0);
     // ---- burst: all K and V rows of this wave that are already in memory (keys < pos) ----
-    uint4 kr[ATT_NI], vr[ATT_NI];
+    uint4 kr[NI], vr[NI];
     const int last = max(pos - 1, 0);
 #pragma unroll
-    for (int i = 0; i < ATT_NI; i++) {
+    for (int i = 0; i < NI; i++) {
         const int jj = min((i * 4 + wave) * KPI + kq, last);
         kr[i] = gload16((jj < pre ? pk : kbase) + ((int64_t)jj * 64 + sub * DPL) * ES);
         vr[i] = gload16((jj < pre ? pv : vbase) + ((int64_t)jj * 64 + sub * DPL) * ES);
@@ -122,7 +127,7 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
             const uint4 ok = *reinterpret_cast<const uint4*>(own_k + sub * 16);
             const uint4 ov4 = *reinterpret_cast<const uint4*>(own_v + sub * 16);
 #pragma unroll
-            for (int i = 0; i < ATT_NI; i++) {
+            for (int i = 0; i < NI; i++) {
                 if (i == i_p && kq == kq_p) { kr[i] = ok; vr[i] = ov4; }
             }
         }
@@ -131,10 +136,10 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
 #pragma unroll
     for (int e = 0; e < DPL; e++) qv[e] = qs[sub * DPL + e];
     // ---- scores ----
-    float sc[ATT_NI];
+    float sc[NI];
     float mx = -INFINITY;
 #pragma unroll
-    for (int i = 0; i < ATT_NI; i++) {
+    for (int i = 0; i < NI; i++) {
         float p;
         if (KVBF16) {
             p = qv[0] * __uint_as_float(kr[i].x << 16) + qv[1] * __uint_as_float(kr[i].x & 0xffff0000u) +
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
     for (int e = 0; e < DPL; e++) ov[e] = 0.0f;
     float l = 0.0f;
 #pragma unroll
-    for (int i = 0; i < ATT_NI; i++) {
+    for (int i = 0; i < NI; i++) {
         const float p = __expf(sc[i] - mx);   // exp(-inf) = 0 for slots past the end (their V rows are valid, finite data)
         l += p;
         if (KVBF16) {
@@ -211,10 +216,27 @@ bool attn_step_supported(const AttnArgs& a) {
            a.pre_len && a.pre_k && a.pre_v && a.qkv_ld % 2 == 0 && a.d_model % 2 == 0;
 }
 
+template <bool KVBF16>
+static void launch_ni(const AttnArgs& a, int ni, dim3 grid, hipStream_t stream) {
+    switch ((ni + 1) / 2) {
+        case 0: case 1: hipLaunchKernelGGL((k_attn_step<KVBF16, 2>), grid, dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL((k_attn_step<KVBF16, 4>), grid, dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL((k_attn_step<KVBF16, 6>), grid, dim3(256), 0, stream, a); break;
+        case 4: hipLaunchKernelGGL((k_attn_step<KVBF16, 8>), grid, dim3(256), 0, stream, a); break;
+        case 5: hipLaunchKernelGGL((k_attn_step<KVBF16, 10>), grid, dim3(256), 0, stream, a); break;
+        case 6: hipLaunchKernelGGL((k_attn_step<KVBF16, 12>), grid, dim3(256), 0, stream, a); break;
+        case 7: hipLaunchKernelGGL((k_attn_step<KVBF16, 14>), grid, dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL((k_attn_step<KVBF16, 16>), grid, dim3(256), 0, stream, a); break;
+    }
+}
+
 void launch_attn_step(const AttnArgs& a, hipStream_t stream) {
     dim3 grid(a.heads, a.rows);
-    if (a.kv_bf16) hipLaunchKernelGGL(k_attn_step<true>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_attn_step<false>, grid, dim3(256), 0, stream, a);
+    const int kpw = 4 * (a.kv_bf16 ? 8 : 4);                                   // keys per wave-instruction round of the block
+    const int keys = a.keys_now > 0 ? std::min(a.keys_now, a.max_keys) : a.max_keys;   // unknown: the whole cache
+    const int ni = std::min(ATT_NI, (keys + kpw - 1) / kpw);
+    if (a.kv_bf16) launch_ni<true>(a, ni, grid, stream);
+    else launch_ni<false>(a, ni, grid, stream);
 }
 
 }  // namespace ptts

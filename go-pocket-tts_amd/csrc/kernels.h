@@ -143,6 +143,7 @@ struct AttnArgs {
     int64_t o_rows_per_batch = 0, o_batch_stride = 0;
     int rows = 0, heads = 0, hd = 64;
     int max_keys = 0;                   // upper bound on keys per query (sizes the LDS score buffer)
+    int keys_now = 0;                   // fused step: host-side upper bound on (cache length + 1) over the rows of THIS launch; 0: unknown
     // fused RoPE + KV append for the AR step (flow_transformer.go:340-347): q,k,v read from a qkv row
     int fused_step = 0; const float* qkv = nullptr; int64_t qkv_ld = 0; int d_model = 0;
     const float* cos_t = nullptr; const float* sin_t = nullptr; int64_t cap = 0;

@@ -234,6 +234,7 @@ void batch_reset(Batch& b) {
     hipStream_t s = b.m->stream;
     const int B = b.B;
     launch_fill_i32(b.st.kv_len, 0, B, s);
+    b.kv_bound = 0;
     launch_fill_i32(b.st.active, 1, B, s);
     launch_fill_i32(b.st.step, 0, B, s);
     launch_fill_i32(b.st.countdown, -1, B, s);
@@ -300,6 +301,7 @@ void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slo
                            b.kc(l), b.vc(l), (int)b.kv_elem(), b.cap, m.stream);
     for (int32_t sl : slots) {
         b.kv_len_host[sl] = v.offset;
+        b.kv_bound = std::max(b.kv_bound, (int)v.offset);
         b.pre_k_host[sl] = v.k.p; b.pre_v_host[sl] = v.v.p; b.pre_len_host[sl] = v.offset;
     }
     h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)b.B * sizeof(int32_t), m.stream);
@@ -322,6 +324,7 @@ void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64
         PTTS_HIP(hipStreamSynchronize(m.stream));
     }
     b.kv_len_host[slot] = (int32_t)offsets[0];
+    b.kv_bound = std::max(b.kv_bound, (int)offsets[0]);
     h2d(b.st.kv_len + slot, &b.kv_len_host[slot], sizeof(int32_t), m.stream);
     b.pre_len_host[slot] = 0;
     h2d(b.pre_len.as<int32_t>() + slot, &b.pre_len_host[slot], sizeof(int32_t), m.stream);
@@ -448,7 +451,10 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
             launch_gemm(g2, s);
         }
     }
-    for (int sl = 0; sl < B; sl++) b.kv_len_host[sl] += (int32_t)(row_offsets[sl + 1] - row_offsets[sl]);
+    for (int sl = 0; sl < B; sl++) {
+        b.kv_len_host[sl] += (int32_t)(row_offsets[sl + 1] - row_offsets[sl]);
+        b.kv_bound = std::max(b.kv_bound, (int)b.kv_len_host[sl]);
+    }
     h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)B * sizeof(int32_t), s);
 }
 
@@ -590,6 +596,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         a.context = -1;
         a.out = attn; a.out_ld = D;
         a.rows = B; a.heads = d.heads; a.max_keys = b.cap;
+        a.keys_now = b.capturing ? 0 : b.kv_bound + 1;
         a.fused_step = 1; a.qkv = qkv; a.qkv_ld = 3 * D; a.d_model = D;
         a.cos_t = m.at<float>(d.rope_cos); a.sin_t = m.at<float>(d.rope_sin); a.cap = b.cap;
         a.pre_k = b.pre_k.as<const void*>(); a.pre_v = b.pre_v.as<const void*>(); a.pre_len = b.pre_len.as<int32_t>(); a.layer = l;
@@ -684,6 +691,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         if (fuse_finish && i == lsd - 1) fin.finish = b.fin_dev.as<StepFinish>();
         finished = step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd);  // current += flow / steps
     }
+    if (!b.capturing) b.kv_bound++;   // every live slot has appended one key
     return finished;
 }
 
@@ -959,11 +967,13 @@ static void capture_step_graph(Batch& b, int lsd) {
     if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
     hipGraph_t g = nullptr;
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
+    b.capturing = true;
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
     step_open(b);
     if (!step_core(b, lsd, b.opened, true))
         launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    b.capturing = false;
     PTTS_HIP(hipStreamEndCapture(m.stream, &g));
     hipError_t e = hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
@@ -976,6 +986,7 @@ static void enqueue_step(Batch& b, int lsd, bool use_graph) {
     Model& m = *b.m;
     if (use_graph) {
         PTTS_HIP(hipGraphLaunch(b.graph, m.stream));
+        b.kv_bound++;
         return;
     }
     const int ld = m.d.ldim;

@@ -97,6 +97,11 @@ struct Batch {
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;
     bool opened = false;     // the last step_open also produced x and fx
+    // host-side upper bound on the cache length of any slot (set by voice/prompt ingestion, +1 per step): lets a step's
+    // attention launch issue only the key loads that can be live (AttnArgs::keys_now).  capturing: a graph is being recorded,
+    // its launches must cover the whole cache
+    int kv_bound = 0;
+    bool capturing = false;
     hipGraphExec_t graph = nullptr;
     int graph_lsd = 0;
     bool graph_noise = false;
