@@ -216,18 +216,12 @@ bool attn_step_supported(const AttnArgs& a) {
            a.pre_len && a.pre_k && a.pre_v && a.qkv_ld % 2 == 0 && a.d_model % 2 == 0;
 }
 
-template <bool KVBF16>
-static void launch_ni(const AttnArgs& a, int ni, dim3 grid, hipStream_t stream) {
-    switch ((ni + 1) / 2) {
-        case 0: case 1: hipLaunchKernelGGL((k_attn_step<KVBF16, 2>), grid, dim3(256), 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((k_attn_step<KVBF16, 4>), grid, dim3(256), 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((k_attn_step<KVBF16, 6>), grid, dim3(256), 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((k_attn_step<KVBF16, 8>), grid, dim3(256), 0, stream, a); break;
-        case 5: hipLaunchKernelGGL((k_attn_step<KVBF16, 10>), grid, dim3(256), 0, stream, a); break;
-        case 6: hipLaunchKernelGGL((k_attn_step<KVBF16, 12>), grid, dim3(256), 0, stream, a); break;
-        case 7: hipLaunchKernelGGL((k_attn_step<KVBF16, 14>), grid, dim3(256), 0, stream, a); break;
-        default: hipLaunchKernelGGL((k_attn_step<KVBF16, 16>), grid, dim3(256), 0, stream, a); break;
+template <bool KVBF16, int NI>
+static void launch_ni(const AttnArgs& a, int ni, dim3 grid, hipStream_t stream) {   // the smallest instantiation that covers ni rounds
+    if constexpr (NI < ATT_NI) {
+        if (ni > NI) { launch_ni<KVBF16, NI + 1>(a, ni, grid, stream); return; }
     }
+    hipLaunchKernelGGL((k_attn_step<KVBF16, NI>), grid, dim3(256), 0, stream, a);
 }
 
 void launch_attn_step(const AttnArgs& a, hipStream_t stream) {
@@ -235,8 +229,8 @@ void launch_attn_step(const AttnArgs& a, hipStream_t stream) {
     const int kpw = 4 * (a.kv_bf16 ? 8 : 4);                                   // keys per wave-instruction round of the block
     const int keys = a.keys_now > 0 ? std::min(a.keys_now, a.max_keys) : a.max_keys;   // unknown: the whole cache
     const int ni = std::min(ATT_NI, (keys + kpw - 1) / kpw);
-    if (a.kv_bf16) launch_ni<true>(a, ni, grid, stream);
-    else launch_ni<false>(a, ni, grid, stream);
+    if (a.kv_bf16) launch_ni<true, 1>(a, ni, grid, stream);
+    else launch_ni<false, 1>(a, ni, grid, stream);
 }
 
 }  // namespace ptts
