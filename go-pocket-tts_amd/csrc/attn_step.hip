@@ -224,11 +224,16 @@ static void launch_ni(const AttnArgs& a, int ni, dim3 grid, hipStream_t stream) 
     hipLaunchKernelGGL((k_attn_step<KVBF16, NI>), grid, dim3(256), 0, stream, a);
 }
 
+int attn_step_keys_per_round(bool kv_bf16) { return 4 * (kv_bf16 ? 8 : 4); }
+int attn_step_rounds(int keys, bool kv_bf16) {
+    const int kpw = attn_step_keys_per_round(kv_bf16);
+    return std::max(1, std::min(ATT_NI, (keys + kpw - 1) / kpw));
+}
+
 void launch_attn_step(const AttnArgs& a, hipStream_t stream) {
     dim3 grid(a.heads, a.rows);
-    const int kpw = 4 * (a.kv_bf16 ? 8 : 4);                                   // keys per wave-instruction round of the block
     const int keys = a.keys_now > 0 ? std::min(a.keys_now, a.max_keys) : a.max_keys;   // unknown: the whole cache
-    const int ni = std::min(ATT_NI, (keys + kpw - 1) / kpw);
+    const int ni = attn_step_rounds(keys, a.kv_bf16 != 0);
     if (a.kv_bf16) launch_ni<true, 1>(a, ni, grid, stream);
     else launch_ni<false, 1>(a, ni, grid, stream);
 }

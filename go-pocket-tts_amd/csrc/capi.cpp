@@ -130,6 +130,14 @@ int ptts_model_share(ptts_model* base, ptts_model** out) {
     });
 }
 
+int ptts_model_set_use_graph(ptts_model* m, int32_t use_graph) {
+    return guard([&] {
+        if (!m || !m->m) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::lock_guard<std::mutex> lock(m->m->mu);   // not under a running generate
+        m->m->opts.use_graph = use_graph ? 1 : 0;
+    });
+}
+
 int ptts_model_open(const char* path, const ptts_opts* opts, ptts_model** out) {
     ptts_plan* pl = nullptr;
     int rc = ptts_plan_create(path, opts, &pl);

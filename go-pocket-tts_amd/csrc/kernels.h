@@ -158,6 +158,8 @@ struct AttnArgs {
 void launch_attention(const AttnArgs& a, hipStream_t stream);   // picks k_attn_step for the fused AR step when the cache fits one burst
 bool attn_step_supported(const AttnArgs& a);
 void launch_attn_step(const AttnArgs& a, hipStream_t stream);
+int attn_step_keys_per_round(bool kv_bf16);       // keys one load round of the block covers (32 bf16 / 16 f32)
+int attn_step_rounds(int keys, bool kv_bf16);     // rounds launch_attn_step issues for a launch bounded by `keys` (1..16)
 bool attn_window_supported(const AttnArgs& a);   // Mimi sliding-window attention on the f32 matrix cores
 void launch_attn_window(const AttnArgs& a, hipStream_t stream);
 

@@ -176,7 +176,7 @@ const float* Model::tcomb_for(int n) {
 // Batch
 // ------------------------------------------------------------------------------------------------
 Batch::~Batch() {
-    if (graph) (void)hipGraphExecDestroy(graph);
+    for (hipGraphExec_t g : graphs) if (g) (void)hipGraphExecDestroy(g);
     if (n_active_pinned) (void)hipHostFree(n_active_pinned);
     if (rows_pinned) (void)hipHostFree(rows_pinned);
 }
@@ -596,7 +596,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         a.context = -1;
         a.out = attn; a.out_ld = D;
         a.rows = B; a.heads = d.heads; a.max_keys = b.cap;
-        a.keys_now = b.capturing ? 0 : b.kv_bound + 1;
+        a.keys_now = b.capturing ? b.capture_keys : b.kv_bound + 1;
         a.fused_step = 1; a.qkv = qkv; a.qkv_ld = 3 * D; a.d_model = D;
         a.cos_t = m.at<float>(d.rope_cos); a.sin_t = m.at<float>(d.rope_sin); a.cap = b.cap;
         a.pre_k = b.pre_k.as<const void*>(); a.pre_v = b.pre_v.as<const void*>(); a.pre_len = b.pre_len.as<int32_t>(); a.layer = l;
@@ -961,31 +961,45 @@ static int resolve_max_steps(const ptts_request& r) {  // runtime_native_safeten
     return ms;
 }
 
-static void capture_step_graph(Batch& b, int lsd) {
+// the graph of one AR step whose attention launches cover `ni` load rounds (captured on first use, kept with the batch)
+static hipGraphExec_t step_graph(Batch& b, int lsd, int ni) {
     Model& m = *b.m;
-    if (b.graph && b.graph_lsd == lsd && b.graph_noise == b.has_noise) return;
-    if (b.graph) { (void)hipGraphExecDestroy(b.graph); b.graph = nullptr; }
+    if (b.graph_lsd != lsd || b.graph_noise != b.has_noise) {
+        for (hipGraphExec_t& g : b.graphs) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+        b.graph_lsd = lsd;
+        b.graph_noise = b.has_noise;
+    }
+    if (b.graphs[ni]) return b.graphs[ni];
     hipGraph_t g = nullptr;
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
     b.capturing = true;
+    b.capture_keys = ni * attn_step_keys_per_round(m.opts.kv == PTTS_KV_BF16);
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    step_open(b);
-    if (!step_core(b, lsd, b.opened, true))
-        launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    hipError_t e = hipSuccess;
+    try {
+        step_open(b);
+        if (!step_core(b, lsd, b.opened, true))
+            launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    } catch (...) {
+        b.capturing = false;
+        (void)hipStreamEndCapture(m.stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        throw;
+    }
     b.capturing = false;
     PTTS_HIP(hipStreamEndCapture(m.stream, &g));
-    hipError_t e = hipGraphInstantiate(&b.graph, g, nullptr, nullptr, 0);
+    e = hipGraphInstantiate(&b.graphs[ni], g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipGraphInstantiate failed: %s", hipGetErrorString(e)));
-    b.graph_lsd = lsd;
-    b.graph_noise = b.has_noise;
+    return b.graphs[ni];
 }
 
 static void enqueue_step(Batch& b, int lsd, bool use_graph) {
     Model& m = *b.m;
     if (use_graph) {
-        PTTS_HIP(hipGraphLaunch(b.graph, m.stream));
+        const int ni = attn_step_rounds(std::min(b.kv_bound + 1, b.cap), m.opts.kv == PTTS_KV_BF16);
+        PTTS_HIP(hipGraphLaunch(step_graph(b, lsd, ni), m.stream));
         b.kv_bound++;
         return;
     }
@@ -1102,7 +1116,6 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     // PTTS_GRAPH=0/1 overrides the option (A/B measurement, tools/eager_vs_graph.py)
     static const int env_graph = [] { const char* e = getenv("PTTS_GRAPH"); return e ? atoi(e) : -1; }();
     const bool use_graph = (env_graph >= 0 ? env_graph != 0 : m.opts.use_graph != 0) && !m.prof.on;
-    if (use_graph) capture_step_graph(b, lsd);
     bool may_stop = false, any_cb = false;
     for (int i = 0; i < B; i++) {
         may_stop |= reqs[idx[i]].eos_threshold < 1e30f;

@@ -102,9 +102,12 @@ struct Batch {
     // its launches must cover the whole cache
     int kv_bound = 0;
     bool capturing = false;
-    hipGraphExec_t graph = nullptr;
+    // graph replay of the AR step (use_graph): one captured step per attention round count (attn_step_rounds: the step
+    // attention's load rounds follow the cache length, and a captured launch cannot change), captured on first use
+    hipGraphExec_t graphs[17] = {};
     int graph_lsd = 0;
     bool graph_noise = false;
+    int capture_keys = 0;    // while capturing: the cache-length bound the recorded attention launches must cover
     // page-locked scratch of the generate loop: [0] live-utterance count, [1, 1+B) n_frames, [1+B, 1+2B) eos_step read back in
     // one copy after the loop; rows_pinned: the B result rows uploaded to the decoder (no pageable staging, no extra sync)
     int32_t* n_active_pinned = nullptr;

@@ -86,7 +86,7 @@ ABI_SYMBOLS = [
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
-    "ptts_model_share", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
+    "ptts_model_share", "ptts_model_set_use_graph", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
 ]
 
@@ -302,6 +302,11 @@ class Model:
         h = C.c_void_p()
         _check(lib().ptts_model_open_planned(plan, C.c_void_p(device_arena_ptr), 1 if fill else 0, C.byref(h)))
         return Model(h.value)
+
+    def set_use_graph(self, on: bool):
+        """ptts_opts.use_graph of an open model: hipGraph replay of the AR step (True) or plain launches (False)."""
+        lib().ptts_model_set_use_graph.argtypes = [C.c_void_p, C.c_int32]
+        _check(lib().ptts_model_set_use_graph(self.h, 1 if on else 0))
 
     def share(self) -> "Model":
         """A second engine over this model's weights (own streams, KV caches, workspaces); this model must outlive it."""

@@ -150,6 +150,8 @@ typedef struct ptts_result {
  * read-only): two engines on one GPU, e.g. behind one dispatcher, let one batch's Mimi decode run beside the next batch's
  * prefill + AR loop.  `base` must outlive the engine; a device voice belongs to the engine it was uploaded to. */
 int  ptts_model_share(ptts_model* base, ptts_model** out);
+/* ptts_opts.use_graph of an open model, changed between calls (A/B measurement, hosts that become short of CPU) */
+int  ptts_model_set_use_graph(ptts_model* m, int32_t use_graph);
 
 /* n_reqs == 1 reproduces GenerateAudio exactly.  n_reqs > 1 is this library's batching
  * extension: independent utterance chunks stepped together (per-row EOS countdown, ragged KV). */

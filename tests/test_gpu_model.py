@@ -687,6 +687,14 @@ def test_long_utterance_beyond_the_one_burst_attention(pkg, tiny):
     assert got.n_frames == ref["n_frames"] == 270
     parity("latents 270 steps", got.latents, ref["latents"], (5e-3, None))
     parity("pcm 270 steps", got.pcm, ref["pcm"], (1e-2, None))
+    # graph replay of the same run: one captured step per attention round count (17 cache-length buckets are crossed here,
+    # then the fallback kernel) -- the same kernels on the same data, so the result is identical
+    gm.set_use_graph(True)
+    try:
+        again = gm.generate_batch([toks], [pkg.RuntimeGenerateConfig(max_steps=270, eos_threshold=1e30, want_latents=True)])[0]
+    finally:
+        gm.set_use_graph(False)
+    assert again.n_frames == 270 and np.array_equal(again.latents, got.latents) and np.array_equal(again.pcm, got.pcm)
 
 
 @pytest.mark.parametrize("kv", ["f32", "bf16"])
