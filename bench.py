@@ -101,7 +101,7 @@ def open_model(pkg, path, wl, rank, world, device):
 def run_workload(pkg, model, wl, prompts, voice, steps, warmup, barrier, sync):
     cfgs = [pkg.RuntimeGenerateConfig(temperature=0.0, eos_threshold=float("inf"), max_steps=wl["frames"],
                                       lsd_decode_steps=1, frames_after_eos=3, device_voice=voice) for _ in range(len(prompts))]
-    toks = [p.tolist() for p in prompts]
+    toks = [np.ascontiguousarray(p, np.int64) for p in prompts]
     out = None
     for _ in range(warmup):
         out = model.generate_batch(toks, cfgs)   # held like in the timed loop: the pinned result pool reaches its steady state (two sets)

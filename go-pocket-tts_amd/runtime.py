@@ -166,11 +166,11 @@ def _f32(a) -> np.ndarray:
 
 
 def _fp(a: Optional[np.ndarray]):
-    return a.ctypes.data_as(_FP) if a is not None else None
+    return C.cast(a.ctypes.data, _FP) if a is not None else None   # (ndarray.ctypes.data_as is three times slower; 64 requests per call)
 
 
 def _ip(a: np.ndarray):
-    return a.ctypes.data_as(_IP)
+    return C.cast(a.ctypes.data, _IP)
 
 
 # ----------------------------------------------------------------------------- reference-shaped types
@@ -374,7 +374,7 @@ class Model:
 
     # -- batched GenerateAudio
     def _fill_request(self, r, toks, cfg, keep):
-        t = np.ascontiguousarray(toks, np.int64)
+        t = toks if type(toks) is np.ndarray and toks.dtype == np.int64 and toks.flags.c_contiguous else np.ascontiguousarray(toks, np.int64)
         keep.append(t)
         r.tokens, r.n_tokens = _ip(t), t.size
         r.temperature, r.eos_threshold = cfg.temperature, min(cfg.eos_threshold, 3.0e38)
@@ -401,8 +401,8 @@ class Model:
         if cfg.cancel is not None:
             r.cancel = cfg.cancel.ctypes.data_as(C.POINTER(C.c_int32))
         r.want_latents = 1 if cfg.want_latents else 0
-        r.pcm_format = 1 if getattr(cfg, "pcm16", False) else 0
-        if getattr(cfg, "pcm_callback", None) is not None:
+        r.pcm_format = 1 if cfg.pcm16 else 0
+        if cfg.pcm_callback is not None:
             dt = np.int16 if r.pcm_format else np.float32
 
             def _pcm(_u, off, n, ptr, f=cfg.pcm_callback, dt=dt):
@@ -411,7 +411,7 @@ class Model:
             pcb = _PCM_CB(_pcm)
             keep.append(pcb)
             r.pcm_callback = pcb
-            r.stream_frames = int(getattr(cfg, "stream_frames", 0))
+            r.stream_frames = int(cfg.stream_frames)
 
     def _take_result(self, rs, cfg) -> "GenerateResult":
         s16 = bool(getattr(cfg, "pcm16", False))   # PCM16 egress: int16 samples encoded on the device
