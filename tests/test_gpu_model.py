@@ -258,10 +258,14 @@ def _eos_case(om, toks, max_steps, fae):
     return ref, np.array(logits)
 
 
-def test_eos_countdown_semantics_exact(pkg, tiny):
-    """runtime_native_safetensors.go:176-190: the EOS step's frame is kept, then exactly frames_after_eos more."""
+@pytest.mark.parametrize("graph", [False, True])
+def test_eos_countdown_semantics_exact(pkg, tiny, graph):
+    """runtime_native_safetensors.go:176-190: the EOS step's frame is kept, then exactly frames_after_eos more -- with the
+    step's kernels launched one by one and replayed from the captured graph (the bookkeeping rides in the step's last kernel
+    either way)."""
     _, _, om, gm = tiny
     rt = pkg.Runtime(gm)
+    gm.set_use_graph(graph)
     toks = [1, 2, 3, 4, 5]
     _, logits = _eos_case(om, toks, 12, 3)
     order = np.argsort(logits)
@@ -275,6 +279,7 @@ def test_eos_countdown_semantics_exact(pkg, tiny):
         assert got.eos_step == ref["eos_step"]
         assert got.n_frames == ref["n_frames"] == min(12, first + fae + 1)
         assert got.pcm.shape[0] == got.n_frames * 1920
+    gm.set_use_graph(False)
 
 
 def test_step_limit_resolution(pkg, tiny):
