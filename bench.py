@@ -226,7 +226,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": wl["dtype"], "data": "synthetic",
         "config": {"workload": f"{args.workload}: {wl['batch']} utterances/GPU x {wl['frames']} frames "
                                f"({wl['frames']*FRAME_SEC:.1f} s each), 25-token prompt + 125-frame voice state, greedy "
-                               f"(temperature 0), hipGraph-captured AR step (46 kernels per frame; one graph per attention round count), Mimi decode to 24 kHz PCM written to host",
+                               f"(temperature 0), hipGraph-captured AR step (46 kernels per frame, five frames per replay; one graph per attention round count), Mimi decode to 24 kHz PCM written to host",
                    "batch_per_gpu": wl["batch"], "frames": wl["frames"], "weights": wl["file"], "kv": "bf16" if wl["kv"] else "f32",
                    "checkpoint": "synthetic, shapes of tts_b6369a24 (seed 1234)", "sharding": f"utterances dealt to {world} rank(s); one weight broadcast at init"},
         "p50_utterance_latency_ms": round(1e3 * statistics.median(lat), 2),

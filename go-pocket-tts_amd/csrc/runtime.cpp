@@ -176,7 +176,7 @@ const float* Model::tcomb_for(int n) {
 // Batch
 // ------------------------------------------------------------------------------------------------
 Batch::~Batch() {
-    for (hipGraphExec_t g : graphs) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& row : graphs) for (hipGraphExec_t g : row) if (g) (void)hipGraphExecDestroy(g);
     if (n_active_pinned) (void)hipHostFree(n_active_pinned);
     if (rows_pinned) (void)hipHostFree(rows_pinned);
 }
@@ -961,26 +961,30 @@ static int resolve_max_steps(const ptts_request& r) {  // runtime_native_safeten
     return ms;
 }
 
-// the graph of one AR step whose attention launches cover `ni` load rounds (captured on first use, kept with the batch)
-static hipGraphExec_t step_graph(Batch& b, int lsd, int ni) {
+// the graph of `nsteps` consecutive AR steps whose attention launches cover `ni` load rounds (captured on first use, kept with
+// the batch).  Several steps per graph: the gap between two replays (~8 us of idle GPU) is paid once per graph.
+static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
     Model& m = *b.m;
-    if (b.graph_lsd != lsd || b.graph_noise != b.has_noise) {
-        for (hipGraphExec_t& g : b.graphs) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    if (b.graph_lsd != lsd || b.graph_noise != b.has_noise || (nsteps > 1 && b.graph_steps != nsteps)) {
+        for (auto& row : b.graphs) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
         b.graph_lsd = lsd;
         b.graph_noise = b.has_noise;
+        if (nsteps > 1) b.graph_steps = nsteps;
     }
-    if (b.graphs[ni]) return b.graphs[ni];
+    hipGraphExec_t& slot = b.graphs[ni][nsteps > 1 ? 1 : 0];
+    if (slot) return slot;
     hipGraph_t g = nullptr;
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
     b.capturing = true;
     b.capture_keys = ni * attn_step_keys_per_round(m.opts.kv == PTTS_KV_BF16);
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    hipError_t e = hipSuccess;
     try {
-        step_open(b);
-        if (!step_core(b, lsd, b.opened, true))
-            launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+        for (int k = 0; k < nsteps; k++) {
+            step_open(b);
+            if (!step_core(b, lsd, b.opened, true))
+                launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+        }
     } catch (...) {
         b.capturing = false;
         (void)hipStreamEndCapture(m.stream, &g);
@@ -989,18 +993,19 @@ static hipGraphExec_t step_graph(Batch& b, int lsd, int ni) {
     }
     b.capturing = false;
     PTTS_HIP(hipStreamEndCapture(m.stream, &g));
-    e = hipGraphInstantiate(&b.graphs[ni], g, nullptr, nullptr, 0);
+    hipError_t e = hipGraphInstantiate(&slot, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (e != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipGraphInstantiate failed: %s", hipGetErrorString(e)));
-    return b.graphs[ni];
+    return slot;
 }
 
-static void enqueue_step(Batch& b, int lsd, bool use_graph) {
+// nsteps > 1 only with use_graph
+static void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps = 1) {
     Model& m = *b.m;
     if (use_graph) {
-        const int ni = attn_step_rounds(std::min(b.kv_bound + 1, b.cap), m.opts.kv == PTTS_KV_BF16);
-        PTTS_HIP(hipGraphLaunch(step_graph(b, lsd, ni), m.stream));
-        b.kv_bound++;
+        const int ni = attn_step_rounds(std::min(b.kv_bound + nsteps, b.cap), m.opts.kv == PTTS_KV_BF16);
+        PTTS_HIP(hipGraphLaunch(step_graph(b, lsd, ni, nsteps), m.stream));
+        b.kv_bound += nsteps;
         return;
     }
     const int ld = m.d.ldim;
@@ -1212,7 +1217,13 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         }, stream_chunks.back().get()));
         f_emitted = f1;
     };
-    for (int step = 0; step < ms_max; step++) {
+    // graph replay without per-step host work (no step callbacks, no cancel flags, no ranges to decode on the way): several
+    // steps per graph.  Slots that finish inside a graph are skipped by every kernel of the remaining steps (active flags).
+    static const int env_gsteps = [] { const char* e = getenv("PTTS_GRAPH_STEPS"); return e ? std::max(1, atoi(e)) : 5; }();   // measured: 1 -> 5: -0.2..-0.6 ms per 125-step batch, 25: -0.1 more
+    bool any_cancel_flag = false;
+    for (int i = 0; i < B; i++) any_cancel_flag |= reqs[idx[i]].cancel != nullptr;
+    const int gsteps = (use_graph && !any_cb && !any_cancel_flag && chunk > ms_max) ? env_gsteps : 1;
+    for (int step = 0; step < ms_max;) {
         int n_cancel = 0;
         for (int i = 0; i < B; i++) {  // ctx.Err() check before every step (:156-159)
             const ptts_request& r = reqs[idx[i]];
@@ -1220,8 +1231,10 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             n_cancel += cancelled[i];
         }
         if (n_cancel == B) break;
-        enqueue_step(b, lsd, use_graph);
-        steps_run = step + 1;
+        const int n_now = (gsteps > 1 && step + gsteps <= ms_max) ? gsteps : 1;
+        enqueue_step(b, lsd, use_graph, n_now);
+        step += n_now;
+        steps_run = step;
         if (steps_run % chunk == 0) { decode_upto(steps_run); emit_upto(steps_run); }
         if (any_cb) {  // StepCallback runs synchronously after the step (:194-196)
             std::vector<int32_t> before = act, broke((size_t)B);
@@ -1229,12 +1242,12 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             d2h(broke.data(), b.st.broke, (size_t)B * 4, s);
             for (int i = 0; i < B; i++) {  // not called for the iteration that leaves through `break` (:185-187)
                 const ptts_request& r = reqs[idx[i]];
-                if (r.step_callback && before[i] && !broke[i] && !cancelled[i]) r.step_callback(r.callback_user, step + 1, ms[i]);
+                if (r.step_callback && before[i] && !broke[i] && !cancelled[i]) r.step_callback(r.callback_user, step, ms[i]);
             }
             bool any = false;
             for (int i = 0; i < B; i++) any |= act[i] != 0;
             if (!any) break;
-        } else if (may_stop && (step % 8) == 7) {
+        } else if (may_stop && step / 8 != (step - n_now) / 8) {   // every eighth step (or the first graph boundary past it)
             PTTS_HIP(hipMemcpyAsync(b.n_active_pinned, b.st.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             PTTS_HIP(hipStreamSynchronize(s));
             if (*b.n_active_pinned <= 0) break;
