@@ -39,8 +39,15 @@ union FragR {
     uint4 q;
 };
 
-template <int C, int H, int NW, bool FINAL, bool WBF16>
+// PERS (last block, bf16 weights): a block stays on its CU and walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Every weight
+// fragment of the three products is copied into LDS once per block, so that the ONLY global fetches of a tile are its rows --
+// and those are requested one tile ahead, right after the previous tile's rows have been consumed (vector loads return in
+// order: with weight fragments fetched from L2 in between, a prefetch would only move the wait).  Without PERS a tile is a
+// chain of four dependent fetches (rows, then each stage's fragments) behind three barriers and the waves sit parked 63 % of
+// their cycles (profiles/r1_pmc_mimi_sq.txt).
+template <int C, int H, int NW, bool FINAL, bool WBF16, bool PERS = false>
 __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
+    static_assert(!PERS || (FINAL && WBF16), "the persistent form is built for the last block with bf16 weights");
     constexpr int TR = NW * 16;                       // rows per tile
     constexpr int HALO = FINAL ? 4 : 2;               // leading rows that are only inputs to later rows
     constexpr int TOUT = TR - HALO;
@@ -49,29 +56,66 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
     constexpr int CM = C / 8 - 1, HM = H / 8 - 1;     // chunk-swizzle masks (16-byte chunks per row - 1)
     constexpr int PLANE = (TR + 2) * ROWB, HPLANE = TR * HROWB;
     constexpr int EU_BYTES = 2 * PLANE;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[EU_BYTES + 2 * HPLANE];
+    constexpr int F1 = (H / 16) * (3 * C / 32), F2 = (C / 16) * (H / 32), FF = 2 * (3 * C / 32);   // weight fragments (1 KiB each): conv k3, conv k1, final hi + lo
+    constexpr int WL_BYTES = PERS ? (F1 + F2 + FF) * 1024 + (H + C + 4) * 4 : 0;   // + the three bias vectors
+    __shared__ __attribute__((aligned(16))) unsigned char smem[EU_BYTES + 2 * HPLANE + WL_BYTES];
     unsigned char* eu_hi = smem;
     unsigned char* eu_lo = smem + PLANE;
     unsigned char* h_hi = smem + EU_BYTES;
     unsigned char* h_lo = h_hi + HPLANE;
+    const uint4* wl1 = reinterpret_cast<const uint4*>(smem + EU_BYTES + 2 * HPLANE);   // PERS: the fragments in LDS
+    const uint4* wl2 = wl1 + F1 * 64;
+    const uint4* wlf = wl2 + F2 * 64;
+    float* bl1 = reinterpret_cast<float*>(smem + EU_BYTES + 2 * HPLANE + (F1 + F2 + FF) * 1024);   // PERS: b1 [H], b2 [C], bf [1] (zeros when absent)
+    float* bl2 = bl1 + H;
+    float* blf = bl2 + C;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
     const int tiles = (a.t1 - a.t0 + TOUT - 1) / TOUT;
-    const int bi = blockIdx.x / tiles, tb = a.t0 + (blockIdx.x % tiles) * TOUT;   // first output row of the tile
-    const int row0 = tb - HALO;                                                     // global row of tile row 0
-    const float* ub = a.u + (int64_t)bi * a.u_bs + (int64_t)a.pad * C;             // row 0 of the utterance
-
-    // ---- A: u -> elu -> hi/lo planes.  Rows before the utterance (beyond its zero history) or past its end are zeros ----
-    {
-        constexpr int V = TR * C / 4 / NTH;           // float4 per thread
-        float4 x[V];
+    const int total = a.B * tiles;
+    constexpr int V = TR * C / 4 / NTH;               // float4 of the tile per thread
+    float4 x[V];
+    auto request_rows = [&](int t) {                  // rows of tile t (clamped addresses; masked when consumed)
+        const int bi_ = t / tiles, row0_ = a.t0 + (t % tiles) * TOUT - HALO;
+        const float* ub_ = a.u + (int64_t)bi_ * a.u_bs + (int64_t)a.pad * C;
 #pragma unroll
         for (int j = 0; j < V; j++) {
             const int e = (tid + j * NTH) * 4, i = e / C, c = e % C;
+            const int gr = row0_ + i;
+            const bool ok = gr >= -a.pad && gr < a.L;
+            x[j] = *reinterpret_cast<const float4*>(ub_ + (int64_t)(ok ? gr : 0) * C + c);
+        }
+    };
+    int tile = blockIdx.x;
+    request_rows(tile);
+    if constexpr (PERS) {
+        uint4* dst = reinterpret_cast<uint4*>(smem + EU_BYTES + 2 * HPLANE);
+        for (int i = tid; i < F1 * 64; i += NTH) dst[i] = reinterpret_cast<const uint4*>(a.w1)[i];
+        for (int i = tid; i < F2 * 64; i += NTH) dst[F1 * 64 + i] = reinterpret_cast<const uint4*>(a.w2)[i];
+        for (int i = tid; i < (FF / 2) * 64; i += NTH) {
+            dst[(F1 + F2) * 64 + i] = reinterpret_cast<const uint4*>(a.wf_hi)[i];
+            dst[(F1 + F2 + FF / 2) * 64 + i] = reinterpret_cast<const uint4*>(a.wf_lo)[i];
+        }
+        // (a global load behind the prefetch would have to wait for it: the biases live in LDS too)
+        if (tid < H) bl1[tid] = a.b1 ? a.b1[tid] : 0.0f;
+        if (tid < C) bl2[tid] = a.b2 ? a.b2[tid] : 0.0f;
+        if (tid == 0) blf[0] = a.bf ? a.bf[0] : 0.0f;
+    }
+  for (;;) {
+    const int bi = tile / tiles, tb = a.t0 + (tile % tiles) * TOUT;   // first output row of the tile
+    const int row0 = tb - HALO;                                         // global row of tile row 0
+    const float* ub = a.u + (int64_t)bi * a.u_bs + (int64_t)a.pad * C; // row 0 of the utterance
+    PcmRow pr{nullptr, 0, 0};                          // fetched here, where the wait for the tile's rows covers it
+    if (FINAL && a.pcm_rows) pr = a.pcm_rows[bi];
+
+    // ---- A: u -> elu -> hi/lo planes.  Rows before the utterance (beyond its zero history) or past its end are zeros ----
+    {
+#pragma unroll
+        for (int j = 0; j < V; j++) {
+            const int e = (tid + j * NTH) * 4, i = e / C;
             const int gr = row0 + i;
             const bool ok = gr >= -a.pad && gr < a.L;
-            x[j] = *reinterpret_cast<const float4*>(ub + (int64_t)(ok ? gr : 0) * C + c);
             if (!ok) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid < 2 * ROWB / 16) {                    // the two history rows in front of the tile only feed halo rows: zeros
@@ -93,13 +137,23 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
     __syncthreads();
 
     const int i_lane = wave * 16 + r16;               // tile row this lane owns in the MFMA operands / results
+    const int gr_lane = row0 + i_lane;
+    const bool in_seq = gr_lane >= 0 && gr_lane < a.L;
+    float4 ur[C / 16];                                // residual operand of stage C
+    if constexpr (PERS) {
+        // the residual rows (L2-hot: this block has just read them) are requested BEFORE the next tile's rows, so that stage C's
+        // wait for them leaves the younger HBM requests in flight
+#pragma unroll
+        for (int n = 0; n < C / 16; n++) ur[n] = *reinterpret_cast<const float4*>(ub + (int64_t)(in_seq ? gr_lane : 0) * C + n * 16 + 4 * g);
+        request_rows(min(tile + (int)gridDim.x, total - 1));   // past the block's last tile: a re-read that is never consumed
+    }
     // ---- B: hidden = elu(conv_k3(eu) + b1) ----
     {
         constexpr int NT = H / 16, KS = 3 * C / 32;
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint4* w1 = reinterpret_cast<const uint4*>(a.w1) + lane;
+        const uint4* w1 = (PERS ? wl1 : reinterpret_cast<const uint4*>(a.w1)) + lane;
         const uint4* w1l = reinterpret_cast<const uint4*>(a.w1_lo) + lane;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
@@ -125,7 +179,7 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {                // lane: row i_lane, hidden channels n*16 + 4g .. +3
             const int ch = n * 16 + 4 * g;
-            const float4 b = a.b1 ? *reinterpret_cast<const float4*>(a.b1 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = PERS ? *reinterpret_cast<const float4*>(bl1 + ch) : (a.b1 ? *reinterpret_cast<const float4*>(a.b1 + ch) : make_float4(0.f, 0.f, 0.f, 0.f));
             unsigned h01, l01, h23, l23;
             split2r(elu_fast(acc[n][0] + b.x), elu_fast(acc[n][1] + b.y), h01, l01);
             split2r(elu_fast(acc[n][2] + b.z), elu_fast(acc[n][3] + b.w), h23, l23);
@@ -142,13 +196,13 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
         f32x4 acc[NT];
 #pragma unroll
         for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int gr = row0 + i_lane;
-        const bool in_seq = gr >= 0 && gr < a.L;
+        const int gr = gr_lane;
         // residual operand: requested before the product, consumed after it (L2-hot: this block has just read the rows)
-        float4 ur[NT];
+        if constexpr (!PERS) {
 #pragma unroll
-        for (int n = 0; n < NT; n++) ur[n] = *reinterpret_cast<const float4*>(ub + (int64_t)(in_seq ? gr : 0) * C + n * 16 + 4 * g);
-        const uint4* w2 = reinterpret_cast<const uint4*>(a.w2) + lane;
+            for (int n = 0; n < NT; n++) ur[n] = *reinterpret_cast<const float4*>(ub + (int64_t)(in_seq ? gr : 0) * C + n * 16 + 4 * g);
+        }
+        const uint4* w2 = (PERS ? wl2 : reinterpret_cast<const uint4*>(a.w2)) + lane;
         const uint4* w2l = reinterpret_cast<const uint4*>(a.w2_lo) + lane;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
@@ -174,7 +228,7 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; n++) {
             const int ch = n * 16 + 4 * g;
-            const float4 b = a.b2 ? *reinterpret_cast<const float4*>(a.b2 + ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = PERS ? *reinterpret_cast<const float4*>(bl2 + ch) : (a.b2 ? *reinterpret_cast<const float4*>(a.b2 + ch) : make_float4(0.f, 0.f, 0.f, 0.f));
             float4 v;
             v.x = elu_fast(ur[n].x + (acc[n][0] + b.x)); v.y = elu_fast(ur[n].y + (acc[n][1] + b.y));
             v.z = elu_fast(ur[n].z + (acc[n][2] + b.z)); v.w = elu_fast(ur[n].w + (acc[n][3] + b.w));
@@ -198,8 +252,8 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
         __syncthreads();
         constexpr int KS = 3 * C / 32;
         f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint4* wfh = reinterpret_cast<const uint4*>(a.wf_hi) + lane;
-        const uint4* wfl = reinterpret_cast<const uint4*>(a.wf_lo) + lane;
+        const uint4* wfh = (PERS ? wlf : reinterpret_cast<const uint4*>(a.wf_hi)) + lane;
+        const uint4* wfl = (PERS ? wlf + (FF / 2) * 64 : reinterpret_cast<const uint4*>(a.wf_lo)) + lane;
 #pragma unroll
         for (int s = 0; s < KS; s++) {
             const int tap = (s * 32) / C, c0 = (s * 32) % C;
@@ -215,14 +269,13 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc, 0, 0, 0);
         }
         const int gr = row0 + i_lane;                 // result column 0 sits in register 0 of lane group 0
-        const float smp = acc[0] + (a.bf ? a.bf[0] : 0.0f);
+        const float smp = acc[0] + (PERS ? blf[0] : (a.bf ? a.bf[0] : 0.0f));
         if (a.pcm_rows) {
             // the tile's TOUT samples are gathered in LDS (the hidden planes are free by now) and leave as 16-byte (f32) or
             // 8-byte (int16) pieces per lane, contiguous over the first lanes of the block: sized for a PCIe write
             float* stage = reinterpret_cast<float*>(h_hi);
             if (g == 0) stage[i_lane] = smp;
             __syncthreads();
-            const PcmRow pr = a.pcm_rows[bi];
             const int lim = min(min(a.t1, a.L), pr.lim);
             const int j = tid * 4, idx = tb + j;
             if (j < TOUT && idx < lim) {
@@ -250,6 +303,11 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
             a.pcm[(int64_t)bi * a.pcm_bs + gr] = smp;
         }
     }
+    if constexpr (!PERS) break;
+    tile += gridDim.x;
+    if (tile >= total) break;
+    __syncthreads();   // the planes and the staging rows are rewritten by the next tile
+  }
 }
 
 bool resblock_supported(const ResArgs& a) {
@@ -264,6 +322,14 @@ static void launch_rb(const ResArgs& a, hipStream_t stream) {
     const int tiles = (a.t1 - a.t0 + tout - 1) / tout;
     dim3 grid((unsigned)(a.B * tiles));
     if (a.final_conv) {
+        if constexpr (C == 64) {
+            static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+            const int resident = 2 * cus;                    // 77 KB of LDS and 116 registers per lane: two blocks per CU
+            if (a.w_bf16 && a.B * tiles >= resident * 8) {   // enough tiles per block to amortise its 28-KB weight copy
+                hipLaunchKernelGGL((k_resblock<C, H, NW, true, true, true>), dim3((unsigned)resident), dim3(NW * 64), 0, stream, a);
+                return;
+            }
+        }
         if (a.w_bf16) hipLaunchKernelGGL((k_resblock<C, H, NW, true, true>), grid, dim3(NW * 64), 0, stream, a);
         else hipLaunchKernelGGL((k_resblock<C, H, NW, true, false>), grid, dim3(NW * 64), 0, stream, a);
     } else {
