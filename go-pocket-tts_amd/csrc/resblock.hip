@@ -1,6 +1,8 @@
 // resblock.hip -- one SEANet residual block of the Mimi decoder as a single kernel (mimi.go:146-164,752-783):
 //     uo = elu( u + conv_k1( elu( conv_k3( elu(u) ) + b1 ) ) + b2 )          (every reader of the sum applies ELU first)
 // and, for the last block, the model's final causal convolution C -> 1 on top of it, writing PCM.
+#include <cstdlib>
+
 #include "kernels.h"
 #include "device_util.h"
 
@@ -39,7 +41,7 @@ union FragR {
     uint4 q;
 };
 
-// PERS (last block, bf16 weights): a block stays on its CU and walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Every weight
+// PERS (bf16 weights): a block stays on its CU and walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...  Every weight
 // fragment of the three products is copied into LDS once per block, so that the ONLY global fetches of a tile are its rows --
 // and those are requested one tile ahead, right after the previous tile's rows have been consumed (vector loads return in
 // order: with weight fragments fetched from L2 in between, a prefetch would only move the wait).  Without PERS a tile is a
@@ -47,7 +49,7 @@ union FragR {
 // their cycles (profiles/r1_pmc_mimi_sq.txt).
 template <int C, int H, int NW, bool FINAL, bool WBF16, bool PERS = false>
 __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
-    static_assert(!PERS || (FINAL && WBF16), "the persistent form is built for the last block with bf16 weights");
+    static_assert(!PERS || WBF16, "the persistent form keeps bf16 weight fragments in LDS");
     constexpr int TR = NW * 16;                       // rows per tile
     constexpr int HALO = FINAL ? 4 : 2;               // leading rows that are only inputs to later rows
     constexpr int TOUT = TR - HALO;
@@ -56,7 +58,7 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
     constexpr int CM = C / 8 - 1, HM = H / 8 - 1;     // chunk-swizzle masks (16-byte chunks per row - 1)
     constexpr int PLANE = (TR + 2) * ROWB, HPLANE = TR * HROWB;
     constexpr int EU_BYTES = 2 * PLANE;
-    constexpr int F1 = (H / 16) * (3 * C / 32), F2 = (C / 16) * (H / 32), FF = 2 * (3 * C / 32);   // weight fragments (1 KiB each): conv k3, conv k1, final hi + lo
+    constexpr int F1 = (H / 16) * (3 * C / 32), F2 = (C / 16) * (H / 32), FF = FINAL ? 2 * (3 * C / 32) : 0;   // weight fragments (1 KiB each): conv k3, conv k1, final hi + lo
     constexpr int WL_BYTES = PERS ? (F1 + F2 + FF) * 1024 + (H + C + 4) * 4 : 0;   // + the three bias vectors
     __shared__ __attribute__((aligned(16))) unsigned char smem[EU_BYTES + 2 * HPLANE + WL_BYTES];
     unsigned char* eu_hi = smem;
@@ -93,14 +95,16 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
         uint4* dst = reinterpret_cast<uint4*>(smem + EU_BYTES + 2 * HPLANE);
         for (int i = tid; i < F1 * 64; i += NTH) dst[i] = reinterpret_cast<const uint4*>(a.w1)[i];
         for (int i = tid; i < F2 * 64; i += NTH) dst[F1 * 64 + i] = reinterpret_cast<const uint4*>(a.w2)[i];
-        for (int i = tid; i < (FF / 2) * 64; i += NTH) {
-            dst[(F1 + F2) * 64 + i] = reinterpret_cast<const uint4*>(a.wf_hi)[i];
-            dst[(F1 + F2 + FF / 2) * 64 + i] = reinterpret_cast<const uint4*>(a.wf_lo)[i];
+        if constexpr (FINAL) {
+            for (int i = tid; i < (FF / 2) * 64; i += NTH) {
+                dst[(F1 + F2) * 64 + i] = reinterpret_cast<const uint4*>(a.wf_hi)[i];
+                dst[(F1 + F2 + FF / 2) * 64 + i] = reinterpret_cast<const uint4*>(a.wf_lo)[i];
+            }
         }
         // (a global load behind the prefetch would have to wait for it: the biases live in LDS too)
         if (tid < H) bl1[tid] = a.b1 ? a.b1[tid] : 0.0f;
         if (tid < C) bl2[tid] = a.b2 ? a.b2[tid] : 0.0f;
-        if (tid == 0) blf[0] = a.bf ? a.bf[0] : 0.0f;
+        if (FINAL && tid == 0) blf[0] = a.bf ? a.bf[0] : 0.0f;
     }
   for (;;) {
     const int bi = tile / tiles, tb = a.t0 + (tile % tiles) * TOUT;   // first output row of the tile
@@ -333,6 +337,17 @@ static void launch_rb(const ResArgs& a, hipStream_t stream) {
         if (a.w_bf16) hipLaunchKernelGGL((k_resblock<C, H, NW, true, true>), grid, dim3(NW * 64), 0, stream, a);
         else hipLaunchKernelGGL((k_resblock<C, H, NW, true, false>), grid, dim3(NW * 64), 0, stream, a);
     } else {
+        if constexpr (C == 128) {
+            if (a.w_bf16) {   // persistent as well: 1458 -> 1055 us at batch 64
+                constexpr int PNW = 6;                                  // 96-row tiles: 139 KB of LDS with the 64 KB of weights, one block per CU
+                static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
+                const int ptiles = (a.t1 - a.t0 + PNW * 16 - 2 - 1) / (PNW * 16 - 2);
+                if (a.B * ptiles >= cus * 8) {
+                    hipLaunchKernelGGL((k_resblock<C, H, PNW, false, true, true>), dim3((unsigned)cus), dim3(PNW * 64), 0, stream, a);
+                    return;
+                }
+            }
+        }
         if (a.w_bf16) hipLaunchKernelGGL((k_resblock<C, H, NW, false, true>), grid, dim3(NW * 64), 0, stream, a);
         else hipLaunchKernelGGL((k_resblock<C, H, NW, false, false>), grid, dim3(NW * 64), 0, stream, a);
     }
