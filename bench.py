@@ -184,7 +184,8 @@ def main():
     ap.add_argument("--workload", default="b64_10s_bf16", choices=list(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-b1", action="store_true")
-    ap.add_argument("--no-two-engines", action="store_true", help="skip the two-engine extra (profiling: its concurrent kernels stretch each other)")
+    ap.add_argument("--no-two-engines", action="store_true", help="skip the two-engine and plain-launch extras (profiling: concurrent kernels stretch each other, "
+                                                                  "and rocprofv3 slows launches that are issued one by one)")
     ap.add_argument("--cpu-frames", type=int, default=63)
     args = ap.parse_args()
 
@@ -231,7 +232,7 @@ def main():
                    "checkpoint": "synthetic, shapes of tts_b6369a24 (seed 1234)", "sharding": f"utterances dealt to {world} rank(s); one weight broadcast at init"},
         "p50_utterance_latency_ms": round(1e3 * statistics.median(lat), 2),
     }
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_two_engines:
         # the same workload with the step's kernels launched one by one instead of replayed from the graph (the library's
         # default: no idle gap between replays; reported beside the headline, which keeps BASELINE's named configuration)
         model.set_use_graph(False)
