@@ -54,6 +54,8 @@ struct GemmArgs {
     int aop = AOP_NONE, epi = EPI_NONE;
 };
 void launch_gemm(const GemmArgs& a, hipStream_t stream);   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
+bool gemm_wres_supported(const GemmArgs& a);   // gemm_wres.hip: K, N <= 256 with the whole weight matrix resident in LDS
+void launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 bool gemm2_supported(const GemmArgs& a);
 void launch_gemm2(const GemmArgs& a, hipStream_t stream);
 bool gemm3_supported(const GemmArgs& a);   // direct-to-register activations, 256-row blocks (gemm3.hip)

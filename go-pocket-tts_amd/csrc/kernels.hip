@@ -148,6 +148,8 @@ void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     // a few rows (prefill of a short prompt, batch-1 serving): the step's weight-streaming kernel beats a tile GEMM that would
     // fill a handful of CUs
     if (a.M <= 64 && a.Wt && skinny_supported(a, 1)) { launch_skinny(a, SkinnyFuse{}, 1, nullptr, stream); return; }
+    static const int wres = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 1; }();   // A/B measurement
+    if (wres && force != 2 && gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
     if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;
