@@ -1,6 +1,8 @@
-// gemm_wres.hip -- many-row GEMM whose whole weight matrix lives in LDS (the last transposed conv of the SEANet decoder:
-// mimi.go:740-788, convtranspose1d.go:73-148 as a [rows x 2*Cin] x [2*Cin x stride*Cout] product with K = N = 256).
+// gemm_wres.hip -- many-row GEMM whose weights live in LDS for the lifetime of a block: the last two transposed convs of the
+// SEANet decoder (mimi.go:740-788, convtranspose1d.go:73-148 as [rows x 2*Cin] x [2*Cin x stride*Cout] products, K = N = 256 and
+// K = 512, N = 640) and the Mimi transformer's linear1 (K = 512, N = 2048, GELU; mimi.go:506-525).
 #include <algorithm>
+#include <cstdlib>
 
 #include "kernels.h"
 #include "device_util.h"
@@ -37,30 +39,38 @@ union FragW {
     uint4 q;
 };
 
-constexpr int WR_N = 256, WR_K = 256, WR_NS = WR_K / 32, WR_RING = 4, WR_NW = 8;
+constexpr int WR_RING = 4, WR_NW = 8;
 
-// N and K are padded to 256 in LDS (columns / k past the matrix are zero weights: their products vanish and are never stored)
-__global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a) {
+// A block owns the column tile [n0, n0 + WR_N) of the output, n0 = ct * WR_N, and a group of row panels; WR_N x WR_K bf16 = 128 KB.
+// With more than one column tile (K = 512: 128-column tiles) the tiles of one row group are placed on ONE XCD
+// (block = xcd + 8 * (ct + ntiles * local group)): they walk the same panels at the same pace, so the rows are fetched from HBM
+// once and re-read from that XCD's L2 by the sibling tiles.
+// Columns / k past the matrix are zero weights in LDS: their products vanish and are never stored.
+template <int WR_N, int WR_K>
+__global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a, int ntiles, int rgl) {
     __shared__ __attribute__((aligned(16))) unsigned char Wl[WR_N * WR_K * 2];   // [k group (8)][column (256)][32 k bf16 = 64 B]
     __shared__ __attribute__((aligned(16))) float Bl[WR_N];                      // bias (a fetch from memory behind the row ring would wait for it)
     constexpr int NT = WR_N / 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int ct = jb % ntiles, grp = xcd * rgl + jb / ntiles, ngrp = 8 * rgl;   // column tile, row group, row groups in all
+    const int n0 = ct * WR_N;
     {   // ---- weights -> LDS, once ----
         constexpr int PPR = WR_K / 8;                 // 16-byte pieces per weight row
         for (int pc = tid; pc < WR_N * PPR; pc += WR_NW * 64) {
             const int n = pc / PPR, kk = pc % PPR;
             uint4 u = make_uint4(0, 0, 0, 0);
-            if (n < a.N && kk * 8 < a.K) u = *reinterpret_cast<const uint4*>((const char*)a.W + ((int64_t)n * a.ldw + kk * 8) * 2);
+            if (n0 + n < a.N && kk * 8 < a.K) u = *reinterpret_cast<const uint4*>((const char*)a.W + ((int64_t)(n0 + n) * a.ldw + kk * 8) * 2);
             *reinterpret_cast<uint4*>(Wl + (kk >> 2) * (WR_N * 64) + n * 64 + (kk & 3) * 16) = u;
         }
     }
-    if (tid < WR_N) Bl[tid] = (a.bias && tid < a.N) ? a.bias[tid] : 0.0f;
+    if (tid < WR_N) Bl[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.0f;
     __syncthreads();
 
     const int npan = (a.M + 31) >> 5;
-    const int stride = gridDim.x * WR_NW;             // panels between two of this wave's
-    const int p0 = blockIdx.x * WR_NW + wave;
+    const int stride = ngrp * WR_NW;                  // panels between two of this wave's
+    const int p0 = grp * WR_NW + wave;
     if (p0 >= npan) return;                           // (after the only barrier)
     const int mine = (npan - p0 + stride - 1) / stride;
     const int nsteps = a.K >> 5;                      // K % 32 == 0 (host)
@@ -123,13 +133,14 @@ __global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a) {
                         const int64_t ro = row_off(a.cmap, min(m, a.M - 1));
 #pragma unroll
                         for (int n = 0; n < NT; n++) {
-                            const int col = n * 16 + 4 * g;
+                            const int lc = n * 16 + 4 * g, col = n0 + lc;
                             float4 v = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
                             acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
                             if (m >= a.M || col >= a.N) continue;   // N % 4 == 0 (host)
-                            const float4 b = *reinterpret_cast<const float4*>(Bl + col);
+                            const float4 b = *reinterpret_cast<const float4*>(Bl + lc);
                             v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
                             if (a.epi == EPI_ELU) { v.x = elu_fast(v.x); v.y = elu_fast(v.y); v.z = elu_fast(v.z); v.w = elu_fast(v.w); }
+                            else if (a.epi == EPI_GELU) { v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); }
                             *reinterpret_cast<float4*>(a.C + ro + col) = v;
                         }
                     }
@@ -141,19 +152,32 @@ __global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a) {
     }
 }
 
-bool gemm_wres_supported(const GemmArgs& a) {
-    // (narrower shapes would multiply zero padding: they stay with k_gemm3)
-    return a.w_bf16 && a.K <= WR_K && a.K > WR_K / 2 && a.K % 32 == 0 && a.N <= WR_N && a.N > WR_N / 2 && a.N % 4 == 0 && a.M >= 2048 && a.aop == AOP_NONE &&
-           (a.epi == EPI_NONE || a.epi == EPI_ELU) && !a.rope_cos && !a.kslice && !a.tail && aligned16(a.A) && a.amap.ld % 4 == 0 &&
-           a.amap.batch_stride % 4 == 0 && a.ldw % 8 == 0 && aligned16(a.W) && aligned16(a.C) && a.cmap.ld % 4 == 0 &&
-           a.cmap.batch_stride % 4 == 0 && (!a.bias || aligned16(a.bias));
+static bool wres_common(const GemmArgs& a) {
+    return a.w_bf16 && a.K % 32 == 0 && a.N % 4 == 0 && a.M >= 2048 && a.aop == AOP_NONE && (a.epi == EPI_NONE || a.epi == EPI_ELU || a.epi == EPI_GELU) &&
+           !a.rope_cos && !a.kslice && !a.tail && aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0 && a.ldw % 8 == 0 &&
+           aligned16(a.W) && aligned16(a.C) && a.cmap.ld % 4 == 0 && a.cmap.batch_stride % 4 == 0;
 }
+static int wres_shape(const GemmArgs& a) {   // 1: 256 x 256 tile, 2: 128 columns x 512 k, 0: not this kernel's
+    if (!wres_common(a)) return 0;
+    if (a.K <= 256 && a.K > 128 && a.N <= 256 && a.N > 128) return 1;              // (narrower shapes would multiply zero padding)
+    static const int wide_k = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 2; }();   // 1: without the K = 512 shapes (A/B measurement)
+    if (wide_k >= 2 && a.K <= 512 && a.K > 256 && a.N >= 512 && (a.N + 127) / 128 <= 32 && a.M >= 16384) return 2;
+    return 0;
+}
+bool gemm_wres_supported(const GemmArgs& a) { return wres_shape(a) != 0; }
 
 void launch_gemm_wres(const GemmArgs& a, hipStream_t stream) {
     static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
-    const int npan = (a.M + 31) / 32;
-    const int blocks = std::max(1, std::min(cus, (npan + WR_NW - 1) / WR_NW));   // 128 KB of LDS: one block per CU
-    hipLaunchKernelGGL(k_gemm_wres, dim3((unsigned)blocks), dim3(WR_NW * 64), 0, stream, a);
+    const int per_xcd = std::max(1, cus / 8);
+    if (wres_shape(a) == 1) {
+        const int npan = (a.M + 31) / 32;
+        const int rgl = std::max(1, std::min(per_xcd, (npan + 8 * WR_NW - 1) / (8 * WR_NW)));   // one block per CU at most
+        hipLaunchKernelGGL((k_gemm_wres<256, 256>), dim3((unsigned)(8 * rgl)), dim3(WR_NW * 64), 0, stream, a, 1, rgl);
+    } else {
+        const int ntiles = (a.N + 127) / 128;
+        const int rgl = std::max(1, per_xcd / ntiles);                                            // row groups per XCD
+        hipLaunchKernelGGL((k_gemm_wres<128, 512>), dim3((unsigned)(8 * rgl * ntiles)), dim3(WR_NW * 64), 0, stream, a, ntiles, rgl);
+    }
 }
 
 }  // namespace ptts
