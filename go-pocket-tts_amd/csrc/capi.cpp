@@ -667,7 +667,13 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         g.R = dR.as<float>(); g.epi = epi;
         g.M = M; g.N = N; g.K = K;
         if (!gemm2_supported(g) || !gemm3_supported(g)) throw Error(PTTS_EINVAL, "shape not supported");
-        auto run = [&](int v, float* c) { GemmArgs h = g; h.C = c; if (v >= 3) { g_gemm3_cfg = v >= 30 ? v - 30 : 0; launch_gemm3(h, nullptr); g_gemm3_cfg = 0; } else launch_gemm2(h, nullptr); };
+        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies)
+        auto run = [&](int v, float* c) {
+            GemmArgs h = g; h.C = c;
+            if (v == 40) launch_gemm(h, nullptr);
+            else if (v >= 3) { g_gemm3_cfg = v >= 30 ? v - 30 : 0; launch_gemm3(h, nullptr); g_gemm3_cfg = 0; }
+            else launch_gemm2(h, nullptr);
+        };
         hipEvent_t e0, e1;
         PTTS_HIP(hipEventCreate(&e0)); PTTS_HIP(hipEventCreate(&e1));
         for (int i = 0; i < 2; i++) run(variant, dC.as<float>());
@@ -682,7 +688,7 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *maxdiff = -1.0f;
         if (nc <= ((size_t)64 << 20)) {
-            run(variant >= 3 ? 2 : 3, dC2.as<float>());
+            run(variant == 40 ? 3 : (variant >= 3 ? 2 : 3), dC2.as<float>());   // the dispatcher's choice is held against k_gemm3 (same k order: equal bits)
             PTTS_HIP(hipDeviceSynchronize());
             std::vector<float> c1(nc), c2(nc);
             down(c1.data(), dC.p, nc * 4); down(c2.data(), dC2.p, nc * 4);

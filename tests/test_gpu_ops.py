@@ -184,3 +184,19 @@ def test_pcm16_kernel_is_bit_exact(pkg, n):
     special = np.array([0.0, 1.0, -1.0, 0.5, -0.5, 2.0, -3.0, np.nan, np.inf, -np.inf, 0.99999, -0.99999, 3.0517578e-05, -3.0517578e-05], np.float32)
     x[: min(n, special.size)] = special[: min(n, special.size)]
     assert np.array_equal(pkg.runtime.op_pcm16(x), O.pcm16(x))
+
+
+@pytest.mark.parametrize("shape", [(4096, 256, 256, 0), (6000, 256, 256, 3), (16384, 640, 512, 0), (16384, 2048, 512, 1), (4100, 192, 224, 0)])
+def test_weights_resident_gemm_equals_the_tile_gemm(pkg, shape):
+    """k_gemm_wres (weights resident in LDS, barrier-free 32-row panels; the last two transposed convs and the Mimi linear1 at
+    many rows) walks k in the same order as k_gemm3 and must give the same bits -- whole 256 x 256 tiles, 128-column tiles of a
+    K = 512 product (N = 640: a ragged last tile), bias, ELU / GELU epilogues, a row count that is no multiple of 32, and a
+    narrower N x K that is zero-padded in LDS."""
+    import ctypes as C
+    M, N, K, epi = shape
+    L = pkg.runtime.lib()
+    L.ptts_debug_gemm.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 2
+    us, md = C.c_float(0), C.c_float(-1)
+    rc = L.ptts_debug_gemm(M, N, K, 1, 40, epi, 1, C.byref(us), C.byref(md))
+    assert rc == 0, L.ptts_last_error().decode()
+    assert md.value == 0.0, (shape, md.value)
