@@ -246,33 +246,39 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
                 if (!(m_ok && kok[j])) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if constexpr ((PRO & PRO_LN) != 0) {   // LayerNorm over the full row (K == row width), biased variance (linear.go:295-309)
-            float s = 0.f;
+            // two elements per instruction where the ISA has it (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32): the prologue runs on
+            // four waves per SIMD and its vector instructions are on the critical path of the launch
+            f32x2 s2 = {0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < NJ; j++) s += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
+            for (int j = 0; j < NJ; j++) s2 += f32x2{xr[j].x, xr[j].z} + f32x2{xr[j].y, xr[j].w};
             // 1/K by v_rcp_f32 (exact for the power-of-two widths of the model, 1 ulp otherwise) and 1/sqrt by v_rsq_f32 (1 ulp)
             // instead of two IEEE divisions and a square root: ~35 vector instructions less on the critical path of every row
             const float rk = __builtin_amdgcn_rcpf((float)p_k);
-            const float mean = wave_sum_dpp(s) * rk;
-            float v = 0.f;
+            const float mean = wave_sum_dpp(s2.x + s2.y) * rk;
+            const f32x2 m2 = {mean, mean};
+            f32x2 v2 = {0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
                 if (kok[j]) {
-                    float d0 = xr[j].x - mean, d1 = xr[j].y - mean, d2 = xr[j].z - mean, d3 = xr[j].w - mean;
-                    v += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+                    const f32x2 da = f32x2{xr[j].x, xr[j].y} - m2, db = f32x2{xr[j].z, xr[j].w} - m2;
+                    v2 += da * da + db * db;
                 }
             }
-            const float inv_std = __builtin_amdgcn_rsqf(wave_sum_dpp(v) * rk + fu.eps);
+            const float inv_std = __builtin_amdgcn_rsqf(wave_sum_dpp(v2.x + v2.y) * rk + fu.eps);
+            const f32x2 is2 = {inv_std, inv_std};
 #pragma unroll
             for (int j = 0; j < NJ; j++) {
-                float4 o;
-                o.x = (xr[j].x - mean) * inv_std; o.y = (xr[j].y - mean) * inv_std; o.z = (xr[j].z - mean) * inv_std; o.w = (xr[j].w - mean) * inv_std;
+                f32x2 oa = (f32x2{xr[j].x, xr[j].y} - m2) * is2, ob = (f32x2{xr[j].z, xr[j].w} - m2) * is2;
                 if constexpr ((PRO & PRO_AFFINE) != 0) {
-                    o.x = o.x * lw[j].x + lb[j].x; o.y = o.y * lw[j].y + lb[j].y; o.z = o.z * lw[j].z + lb[j].z; o.w = o.w * lw[j].w + lb[j].w;
+                    oa = oa * f32x2{lw[j].x, lw[j].y} + f32x2{lb[j].x, lb[j].y};
+                    ob = ob * f32x2{lw[j].z, lw[j].w} + f32x2{lb[j].z, lb[j].w};
                 }
                 if constexpr ((PRO & PRO_MOD) != 0) {
-                    o.x = o.x * (lc[j].x + 1.0f) + lh[j].x; o.y = o.y * (lc[j].y + 1.0f) + lh[j].y;
-                    o.z = o.z * (lc[j].z + 1.0f) + lh[j].z; o.w = o.w * (lc[j].w + 1.0f) + lh[j].w;
+                    const f32x2 one = {1.0f, 1.0f};
+                    oa = oa * (f32x2{lc[j].x, lc[j].y} + one) + f32x2{lh[j].x, lh[j].y};
+                    ob = ob * (f32x2{lc[j].z, lc[j].w} + one) + f32x2{lh[j].z, lh[j].w};
                 }
+                float4 o = make_float4(oa.x, oa.y, ob.x, ob.y);
                 if (!kok[j]) o = make_float4(0.f, 0.f, 0.f, 0.f);
                 xr[j] = o;
                 if (fu.y_out && blockIdx.x == 0 && m_ok && kok[j]) *reinterpret_cast<float4*>(fu.y_out + (int64_t)m * p_k + (lane + 64 * j) * 4) = o;
