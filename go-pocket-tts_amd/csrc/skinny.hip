@@ -176,10 +176,16 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         // dispatch is cold in the scalar cache and each miss is a round trip to memory (~0.5 us); left to itself the compiler
         // loads a field where it is first used, behind a branch on an earlier field, which chained five to six such round
         // trips through the kernel (measured with tools/stamps_skinny.py: 2.3 us before the first weight load was issued).
-        asm volatile("" ::"s"(a.A), "s"(a.amap.ld), "s"(a.W), "s"(a.ldw), "s"(a.Wt), "s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R),
-                     "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha), "s"(a.tail), "s"(a.M), "s"(a.N), "s"(a.K), "s"(a.epi), "s"(splitk), "s"(partial));
-        asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.pgate), "s"(fu.ldpg), "s"(fu.x_out), "s"(fu.ln),
-                     "s"(fu.ln_w), "s"(fu.ln_b), "s"(fu.eps), "s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod), "s"(fu.y_out), "s"(fu.fin));
+        // Only what the variant reads is pinned: everything listed is live in SGPRs at this point at once, and the most-launched
+        // fused-prologue variant was spilling 15 scalars to vector lanes (v_writelane / v_readlane on the critical path) to make room
+        // for fields it never touches (the copies of Wt / A / lda / M / N / K arrive as leading arguments).
+        asm volatile("" ::"s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R), "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha),
+                     "s"(a.tail), "s"(a.epi), "s"(splitk), "s"(partial));
+        if constexpr ((PRO & PRO_PARTIAL) != 0) asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.x_out));
+        if constexpr ((PRO & PRO_LN) != 0) asm volatile("" ::"s"(fu.eps), "s"(fu.y_out));
+        if constexpr ((PRO & PRO_AFFINE) != 0) asm volatile("" ::"s"(fu.ln_w), "s"(fu.ln_b));
+        if constexpr ((PRO & PRO_MOD) != 0) asm volatile("" ::"s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod));
+        if constexpr (FIN) asm volatile("" ::"s"(fu.fin));
         float4 lw[(PRO & PRO_AFFINE) ? NJ : 1], lb[(PRO & PRO_AFFINE) ? NJ : 1], lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
         auto load_params = [&]() {
             if constexpr ((PRO & PRO_AFFINE) != 0) {
