@@ -40,15 +40,18 @@ __device__ __forceinline__ uint4 gload16(const char* p) {
 }
 template <class T> using cptr = const __attribute__((address_space(4))) T*;
 
+// The five leading pointers are copies of a.seg_len / a.active / a.pre_len / a.pre_k / a.pre_v: built with
+// -amdgpu-kernarg-preload-count they arrive in SGPRs with the dispatch, so the per-utterance scalar loads below leave at once
+// instead of behind the first round trip for the argument block.
 template <bool KVBF16, int NI>
-__global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
+__global__ __launch_bounds__(256) void k_attn_step(const int32_t* p_seg_len, const int32_t* p_active, const int32_t* p_pre_len, const void* const* p_pre_k,
+                                                   const void* const* p_pre_v, AttnArgs a) {
     constexpr int LPK = KVBF16 ? 8 : 16;       // lanes per key (16 B each)
     constexpr int KPI = 64 / LPK;              // keys per wave-instruction
     constexpr int DPL = 64 / LPK;              // head dims per lane (8 or 4)
     constexpr int ES = KVBF16 ? 2 : 4;
-    asm volatile("" ::"s"(a.k), "s"(a.v), "s"(a.k_seg_stride), "s"(a.k_head_stride), "s"(a.seg_len), "s"(a.active), "s"(a.out), "s"(a.out_ld),
-                 "s"(a.qkv), "s"(a.qkv_ld), "s"(a.d_model), "s"(a.cos_t), "s"(a.sin_t), "s"(a.pre_k), "s"(a.pre_v), "s"(a.pre_len), "s"(a.layer),
-                 "s"(a.heads));
+    asm volatile("" ::"s"(a.k), "s"(a.v), "s"(a.k_seg_stride), "s"(a.k_head_stride), "s"(a.out), "s"(a.out_ld), "s"(a.qkv), "s"(a.qkv_ld), "s"(a.d_model),
+                 "s"(a.cos_t), "s"(a.sin_t), "s"(a.layer), "s"(a.heads));
     __shared__ float qs[64];
     __shared__ __attribute__((aligned(16))) unsigned char own_k[64 * ES], own_v[64 * ES];   // this step's k, v in cache format
     __shared__ __attribute__((aligned(16))) float red_m[16];
@@ -57,11 +60,11 @@ __global__ __launch_bounds__(256) void k_attn_step(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x, seg = blockIdx.y;
     // per-utterance scalars: one batch of scalar loads
-    const int pos = ((cptr<int32_t>)a.seg_len)[seg];
-    const int live = ((cptr<int32_t>)a.active)[seg];
-    const int pre = ((cptr<int32_t>)a.pre_len)[seg];
-    const char* pk0 = (const char*)((cptr<const void*>)a.pre_k)[seg];
-    const char* pv0 = (const char*)((cptr<const void*>)a.pre_v)[seg];
+    const int pos = ((cptr<int32_t>)p_seg_len)[seg];
+    const int live = ((cptr<int32_t>)p_active)[seg];
+    const int pre = ((cptr<int32_t>)p_pre_len)[seg];
+    const char* pk0 = (const char*)((cptr<const void*>)p_pre_k)[seg];
+    const char* pv0 = (const char*)((cptr<const void*>)p_pre_v)[seg];
     asm volatile("" ::"s"(pos), "s"(live), "s"(pre), "s"(pk0), "s"(pv0));
     char* kbase = (char*)a.k + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * ES;
     char* vbase = (char*)a.v + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * ES;
@@ -221,7 +224,7 @@ static void launch_ni(const AttnArgs& a, int ni, dim3 grid, hipStream_t stream) 
     if constexpr (NI < ATT_NI) {
         if (ni > NI) { launch_ni<KVBF16, NI + 1>(a, ni, grid, stream); return; }
     }
-    hipLaunchKernelGGL((k_attn_step<KVBF16, NI>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((k_attn_step<KVBF16, NI>), grid, dim3(256), 0, stream, a.seg_len, a.active, a.pre_len, a.pre_k, a.pre_v, a);
 }
 
 int attn_step_keys_per_round(bool kv_bf16) { return 4 * (kv_bf16 ? 8 : 4); }
