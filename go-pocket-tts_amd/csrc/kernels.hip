@@ -728,6 +728,25 @@ __global__ __launch_bounds__(256) void k_step_begin(StepState s, const float* la
                                                     float* x, const void* w_pj, const float* b_pj, int d_pj, float* fx) {
     __shared__ float vin[64], vst[64];
     const int bi = blockIdx.y, tid = threadIdx.x;
+    // the thread's weight row is requested first: it does not depend on the step's input, whose own chain (step counter -> latent
+    // row -> LDS -> barrier) then runs under that fetch instead of in front of it.  ldim <= 64 (host), ldim % 4 == 0.
+    const int n = blockIdx.x * 256 + tid;
+    const bool have = w_in && n < d_in + d_pj;
+    const bool first = n < d_in;
+    const int row = first ? n : n - d_in;
+    const char* wrow = (const char*)(first ? w_in : w_pj) + (int64_t)(have ? row : 0) * ldim * (WBF16 ? 2 : 4);
+    constexpr int WQ = 16;                              // 4-k groups of a 64-wide row
+    uint2 wb[WBF16 ? WQ : 1];
+    float4 wf[WBF16 ? 1 : WQ];
+    if (w_in) {
+#pragma unroll
+        for (int q = 0; q < WQ; q++) {
+            if (q * 4 < ldim) {
+                if constexpr (WBF16) wb[q] = *reinterpret_cast<const uint2*>(wrow + q * 8);
+                else wf[q] = *reinterpret_cast<const float4*>(wrow + q * 16);
+            }
+        }
+    }
     if (tid < ldim) {
         const int st = s.step[bi];
         const float v = st == 0 ? NAN : latents[(int64_t)bi * lat_stride + (int64_t)(st - 1) * ldim + tid];
@@ -738,24 +757,24 @@ __global__ __launch_bounds__(256) void k_step_begin(StepState s, const float* la
         if (blockIdx.x == 0) { in32[bi * ldim + tid] = vi; x0[bi * ldim + tid] = vs; }
     }
     __syncthreads();
-    const int n = blockIdx.x * 256 + tid;
-    if (!w_in || n >= d_in + d_pj) return;
-    const bool first = n < d_in;
-    const int row = first ? n : n - d_in;
+    if (!have) return;
     const float* vec = first ? vin : vst;
-    const char* wrow = (const char*)(first ? w_in : w_pj) + (int64_t)row * ldim * (WBF16 ? 2 : 4);
     const float* bias = first ? b_in : b_pj;
     float acc = 0.0f;
-    for (int k = 0; k < ldim; k += 4) {   // ldim % 4 == 0 (host)
-        float w0, w1, w2, w3;
-        if (WBF16) {
-            const uint2 u = *reinterpret_cast<const uint2*>(wrow + k * 2);
-            w0 = __uint_as_float(u.x << 16); w1 = __uint_as_float(u.x & 0xffff0000u); w2 = __uint_as_float(u.y << 16); w3 = __uint_as_float(u.y & 0xffff0000u);
-        } else {
-            const float4 u = *reinterpret_cast<const float4*>(wrow + k * 4);
-            w0 = u.x; w1 = u.y; w2 = u.z; w3 = u.w;
+#pragma unroll
+    for (int q = 0; q < WQ; q++) {
+        if (q * 4 < ldim) {
+            const int k = q * 4;
+            float w0, w1, w2, w3;
+            if constexpr (WBF16) {
+                const uint2 u = wb[q];
+                w0 = __uint_as_float(u.x << 16); w1 = __uint_as_float(u.x & 0xffff0000u); w2 = __uint_as_float(u.y << 16); w3 = __uint_as_float(u.y & 0xffff0000u);
+            } else {
+                const float4 u = wf[q];
+                w0 = u.x; w1 = u.y; w2 = u.z; w3 = u.w;
+            }
+            acc = fmaf(w0, vec[k], acc); acc = fmaf(w1, vec[k + 1], acc); acc = fmaf(w2, vec[k + 2], acc); acc = fmaf(w3, vec[k + 3], acc);
         }
-        acc = fmaf(w0, vec[k], acc); acc = fmaf(w1, vec[k + 1], acc); acc = fmaf(w2, vec[k + 2], acc); acc = fmaf(w3, vec[k + 3], acc);
     }
     acc += bias ? bias[row] : 0.0f;
     if (first) x[(int64_t)bi * d_in + row] = acc;
