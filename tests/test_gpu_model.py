@@ -731,3 +731,25 @@ def test_prefill_ragged_long_prompts_on_the_matrix_cores(pkg, tiny, kv):
     b.close()
     if own:
         own.close()
+
+
+def test_ragged_batch_graph_replay_equals_plain_launches(pkg, tiny):
+    """Five steps per replayed graph, one captured graph per attention round count: utterances that stop inside a graph (step
+    limits 3 / 7 / 12, one on its EOS countdown) must come out exactly as with the kernels launched one by one."""
+    _, _, om, gm = tiny
+    toks = [[10, 20, 30], [5, 6], [7, 8, 9, 11]]
+    _, logits = _eos_case(om, toks[2], 12, 2)
+    thr = float(np.sort(logits)[-2]) - 1e-3          # the second-largest logit: EOS fires somewhere inside the run
+    cfgs = [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=3, want_latents=True),
+            pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=7, want_latents=True),
+            pkg.RuntimeGenerateConfig(eos_threshold=thr, max_steps=12, frames_after_eos=2, want_latents=True)]
+    plain = gm.generate_batch(toks, cfgs)
+    gm.set_use_graph(True)
+    try:
+        graph = gm.generate_batch(toks, cfgs)
+    finally:
+        gm.set_use_graph(False)
+    assert [o.n_frames for o in plain][:2] == [3, 7] and plain[2].n_frames < 12
+    for a, b in zip(plain, graph):
+        assert a.n_frames == b.n_frames and a.eos_step == b.eos_step
+        assert np.array_equal(a.latents, b.latents) and np.array_equal(a.pcm, b.pcm)
