@@ -73,6 +73,13 @@ class _Result(C.Structure):
                 ("status", C.c_int32), ("pcm16", C.POINTER(C.c_int16)), ("reserved", C.c_int32 * 2)]
 
 
+# the same layout as a numpy record (generate_batch reads a whole batch of results as one table)
+_RESULT_DTYPE = np.dtype({"names": ["pcm", "n_samples", "latents", "n_frames", "eos_step", "status", "pcm16", "reserved"],
+                          "formats": ["<u8", "<i8", "<u8", "<i4", "<i4", "<i4", "<u8", ("<i4", 2)],
+                          "offsets": [_Result.pcm.offset, _Result.n_samples.offset, _Result.latents.offset, _Result.n_frames.offset,
+                                      _Result.eos_step.offset, _Result.status.offset, _Result.pcm16.offset, _Result.reserved.offset],
+                          "itemsize": C.sizeof(_Result)})
+
 _lib = None
 
 # every symbol include/ptts.h declares (tests check that the built library exports all of them)
@@ -214,18 +221,23 @@ class RuntimeGenerateConfig:
     stream_frames: int = 0
 
 
+def _free_addr(addr: int):
+    """Hand one result buffer back to the library's page-locked pool."""
+    r = _Result()
+    r.pcm = C.cast(C.c_void_p(addr), _FP)
+    lib().ptts_free_result(C.byref(r))
+
+
 class _OwnedBuffer:
     """A result buffer handed over by the library: exposes it to numpy without a copy and frees it on collection."""
 
     def __init__(self, ptr, n: int, typestr: str):
-        self._addr = C.cast(ptr, C.c_void_p).value
+        self._addr = ptr if type(ptr) is int else C.cast(ptr, C.c_void_p).value
         self.__array_interface__ = {"shape": (n,), "typestr": typestr, "data": (self._addr, False), "version": 3}
 
     def __del__(self):
         if self._addr and sys is not None and not sys.is_finalizing():
-            r = _Result()
-            r.pcm = C.cast(C.c_void_p(self._addr), _FP)
-            lib().ptts_free_result(C.byref(r))
+            _free_addr(self._addr)
             self._addr = None
 
 
@@ -439,13 +451,31 @@ class Model:
             self._fill_request(reqs[i], toks, cfg, keep)
         rc = lib().ptts_generate(self.h, reqs, n, ress)
         out = []
+        raw = np.frombuffer(ress, dtype=_RESULT_DTYPE, count=n)   # the result structs as one table: no per-field ctypes objects
         try:
             _check(rc)
-            for i in range(n):
-                out.append(self._take_result(ress[i], cfgs[i]))
+            if raw["latents"].any():                                # want_latents: the general (slower) path
+                for i in range(n):
+                    out.append(self._take_result(ress[i], cfgs[i]))
+            else:
+                nf, es, ns = raw["n_frames"].tolist(), raw["eos_step"].tolist(), raw["n_samples"].tolist()
+                a32, a16 = raw["pcm"].tolist(), raw["pcm16"].tolist()
+                raw["pcm"][:] = 0                                   # ownership moves to the arrays below (zero-copy, freed on collection)
+                raw["pcm16"][:] = 0
+                for i in range(n):
+                    s16 = a16[i] != 0
+                    addr = a16[i] if s16 else a32[i]
+                    if ns[i] and addr:
+                        pcm = np.asarray(_OwnedBuffer(addr, ns[i], "<i2" if s16 else "<f4"))
+                    else:
+                        if addr:
+                            _free_addr(addr)
+                        pcm = np.zeros(0, np.int16 if cfgs[i].pcm16 else np.float32)
+                    out.append(GenerateResult(pcm, nf[i], es[i], None))
         finally:
-            for i in range(n):
-                lib().ptts_free_result(C.byref(ress[i]))
+            if raw["pcm"].any() or raw["pcm16"].any() or raw["latents"].any():
+                for i in range(n):
+                    lib().ptts_free_result(C.byref(ress[i]))
         return out
 
 
