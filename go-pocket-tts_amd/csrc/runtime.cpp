@@ -333,7 +333,7 @@ void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64
 // FlowLM.PromptText -> flowTransformer.prefill (flow_lm.go:155-187, flow_transformer.go:749-771), all slots at once,
 // ragged prompts packed as rows.  The hidden output is discarded by the reference, so the last layer stops after
 // its keys/values are in the cache.
-static int pick_split(int M, int N, int K);
+static int pick_split(int M, int N, int K, bool w_bf16 = false);
 
 void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
     Model& m = *b.m;
@@ -489,8 +489,12 @@ struct Pending {
     const float* bias = nullptr;
 };
 
-static int pick_split(int M, int N, int K) {
+static int pick_split(int M, int N, int K, bool w_bf16) {
     if (K <= 1024) return 1;   // a whole-K block is one memory burst; splitting pays only when K forces several bursts
+    // a full batch on bf16 weights: 2048-deep slices (k_skinny NJ = 8, 32-column blocks): the producer's blocks fetch a third more,
+    // every consumer block of the next launch re-reads half as many planes
+    static const bool deep = [] { const char* e = getenv("PTTS_DEEP_SLICES"); return !e || atoi(e) != 0; }();   // A/B measurement
+    if (deep && w_bf16 && M > 32 && K >= 4096 && K % 2048 == 0 && ((N + 31) / 32) * ((M + 15) / 16) * (K / 2048) >= 200) return K / 2048;
     int need = (K + 1023) / 1024;
     int blocks = ((N + 63) / 64) * ((M + 15) / 16);
     int want = (256 + blocks - 1) / blocks;
@@ -613,7 +617,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         }
         {
             GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
-            const int S = pick_split(B, D, d.ffn);
+            const int S = pick_split(B, D, d.ffn, g2.w_bf16 != 0);
             if (S > 1 && skinny_supported(g2, S)) {
                 step_gemm(m, g2, SkinnyFuse{}, S, b.partial.as<float>());
                 pend.partial = b.partial.as<float>(); pend.splitk = S; pend.pstride = (int64_t)B * D; pend.bias = m.at<float>(L.l2.b);

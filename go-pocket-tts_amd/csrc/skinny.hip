@@ -1,6 +1,8 @@
 // skinny.hip -- the AR step's weight-streaming linear (the kernel the roofline in bench.py prices).
 #include <hip/hip_ext.h>
 
+#include "../../include/ptts.h"
+#include "common.h"
 #include "kernels.h"
 #include "device_util.h"
 
@@ -37,6 +39,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int SK_KMAX = 1024;   // K slice per block (LDS image: 2 x 16 rows x 2 KB = 64 KB)
+constexpr int SK_KMAX2 = 2048;  // ... for the plain (no fused prologue) split-K launches: NJ = 8, image 2 x 16 rows x 4 KB = 128 KB
 
 // (a, b) -> packed bf16 hi pair and bf16 lo pair with a = hi + lo (round-to-nearest-even, NaN stays NaN)
 __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
@@ -57,7 +60,8 @@ union Frag8 {
 // prologue variants (template parameter PRO)
 constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8;
 
-// NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024).
+// NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024, 8: <= 2048 -- halves the split-K planes the
+// consumer of a 4096-deep product has to re-read).
 // CG: 16-column groups per block (4: 64 columns x 4 K parts; 1: 16 columns x 16 K parts -- four times the blocks, for
 // launches whose 64-column grid would leave most of the chip idle: batch <= 16, the reference's own batch-1 case)
 // FIN: the launch carries the AR step's bookkeeping (SkinnyFuse::fin) -- a template parameter so that the other variants do
@@ -75,8 +79,9 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     constexpr int WV = WBF16 ? 4 : 8;          // 16-byte weight loads per lane per super-step
     // LDS image: row r (0..15) = 2048 B = 128 chunks of 16 B; chunk c is stored at c ^ r, so the 16 lanes that read
     // the same logical chunk of 16 different rows hit 16 different bank groups
-    __shared__ __attribute__((aligned(16))) unsigned char Xh[16 * 2048];
-    __shared__ __attribute__((aligned(16))) unsigned char Xl[16 * 2048];
+    constexpr int RB = NJ > 4 ? 4096 : 2048, CMASK = RB / 16 - 1;   // bytes and 16-byte chunks (- 1) per image row
+    __shared__ __attribute__((aligned(16))) unsigned char Xh[16 * RB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xl[16 * RB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches
     constexpr int KP = 16 / CG;                // K parts per column group
     const int cg = wave % CG, kq4 = wave / CG;
@@ -298,7 +303,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             unsigned h01, l01, h23, l23;
             split2(xr[j].x, xr[j].y, h01, l01);
             split2(xr[j].z, xr[j].w, h23, l23);
-            const int off = wave * 2048 + ((((k >> 3) ^ wave) & 127) << 4) + ((k & 4) << 1);
+            const int off = wave * RB + ((((k >> 3) ^ wave) & CMASK) << 4) + ((k & 4) << 1);
             *reinterpret_cast<uint2*>(&Xh[off]) = make_uint2(h01, h23);
             *reinterpret_cast<uint2*>(&Xl[off]) = make_uint2(l01, l23);
         }
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 #pragma unroll
         for (int s = 0; s < 4; s++) {
             const int c = (ss_lo + t) * 16 + q * 4 + s;            // logical 16-byte chunk = 8 k
-            const int off = i16 * 2048 + (((c ^ i16) & 127) << 4);
+            const int off = i16 * RB + (((c ^ i16) & CMASK) << 4);
             Frag8 xh, xl;
             xh.q = *reinterpret_cast<const uint4*>(&Xh[off]);
             xl.q = *reinterpret_cast<const uint4*>(&Xl[off]);
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 bool skinny_supported(const GemmArgs& a, int splitk) {
     if (splitk < 1) splitk = 1;
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= SK_KMAX && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
+    return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= (splitk > 1 && a.w_bf16 ? SK_KMAX2 : SK_KMAX) && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
            a.amap.ld % 4 == 0 && aligned16(a.A) && aligned16(a.W) && a.ldw % 8 == 0 && a.aop == AOP_NONE;
 }
 
@@ -461,7 +466,9 @@ template <bool WBF16, int PRO>
 static void launch_pro(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
     if (kslice <= 512) launch_nj<WBF16, PRO, 2>(a, fu, splitk, partial, grid, stream);
-    else launch_nj<WBF16, PRO, 4>(a, fu, splitk, partial, grid, stream);
+    else if (kslice <= SK_KMAX) launch_nj<WBF16, PRO, 4>(a, fu, splitk, partial, grid, stream);
+    else if constexpr (PRO == 0 && WBF16) launch_cg<WBF16, 0, 8, 2>(a, fu, splitk, partial, stream);   // 2048-deep slices: 32-column blocks x 8 K parts
+    else throw Error(PTTS_EINVAL, "ptts-hip: internal: K slice too deep for this variant of the step kernel");
 }
 
 template <bool WBF16>
