@@ -58,7 +58,7 @@ union Frag8 {
 };
 
 // prologue variants (template parameter PRO)
-constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8;
+constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_TWO = 16;   // PRO_TWO (with PRO_PARTIAL): exactly two planes
 
 // NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024, 8: <= 2048 -- halves the split-K planes the
 // consumer of a 4096-deep product has to re-read).
@@ -215,6 +215,14 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 #pragma unroll
             for (int j = 0; j < NJ; j++) ps[j] = *reinterpret_cast<const float4*>(pp + kc[j]);
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr ((PRO & PRO_TWO) != 0) {   // two planes (2048-deep slices of a 4096-deep product): exactly one more request per column group
+                float4 p1[NJ];
+#pragma unroll
+                for (int j = 0; j < NJ; j++) p1[j] = *reinterpret_cast<const float4*>(pp + (int64_t)fu.pstride + kc[j]);
+#pragma unroll
+                for (int j = 0; j < NJ; j++) { ps[j].x += p1[j].x; ps[j].y += p1[j].y; ps[j].z += p1[j].z; ps[j].w += p1[j].w; }
+                __builtin_amdgcn_sched_barrier(0);   // the LayerNorm vectors are requested after these have been consumed (register budget)
+            } else
             for (int z0 = 1; z0 < fu.psplit; z0 += 3) {   // three more slices per round trip
                 float4 p[3][NJ];
 #pragma unroll
@@ -477,7 +485,10 @@ static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float*
     switch (pro) {
         case 0: launch_pro<WBF16, 0>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN | PRO_AFFINE: launch_pro<WBF16, PRO_LN | PRO_AFFINE>(a, fu, splitk, partial, grid, stream); break;
-        case PRO_LN | PRO_AFFINE | PRO_PARTIAL: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL>(a, fu, splitk, partial, grid, stream); break;
+        case PRO_LN | PRO_AFFINE | PRO_PARTIAL:
+            if (fu.psplit == 2) launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL | PRO_TWO>(a, fu, splitk, partial, grid, stream);
+            else launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL>(a, fu, splitk, partial, grid, stream);
+            break;
         case PRO_LN | PRO_AFFINE | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN: launch_pro<WBF16, PRO_LN>(a, fu, splitk, partial, grid, stream); break;
