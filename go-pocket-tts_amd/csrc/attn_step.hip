@@ -234,6 +234,7 @@ int attn_step_rounds(int keys, bool kv_bf16) {
 }
 
 void launch_attn_step(const AttnArgs& a, hipStream_t stream) {
+    note_launch("k_attn_step");
     dim3 grid(a.heads, a.rows);
     const int keys = a.keys_now > 0 ? std::min(a.keys_now, a.max_keys) : a.max_keys;   // unknown: the whole cache
     const int ni = attn_step_rounds(keys, a.kv_bf16 != 0);

@@ -198,6 +198,7 @@ bool attn_window_supported(const AttnArgs& a) {
 }
 
 void launch_attn_window(const AttnArgs& a, hipStream_t stream) {
+    note_launch(a.rag_off ? "k_attn_window<ragged>" : "k_attn_window");
     const int qtiles = (a.rows_per_seg + 31) / 32;   // ragged: rows_per_seg is the longest segment
     const int segs = a.rag_off ? a.rag_segs : a.rows / a.rows_per_seg;
     dim3 grid(a.heads, (unsigned)(segs * ((qtiles + 3) / 4)));

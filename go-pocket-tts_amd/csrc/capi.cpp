@@ -72,7 +72,22 @@ void ptts_default_opts(ptts_opts* o) {
 }
 
 const char* ptts_last_error(void) { return last_error_ref().c_str(); }
-const char* ptts_version(void) { return "ptts-hip 0.1 gfx950"; }
+const char* ptts_version(void) { return "ptts-hip 0.2 gfx950"; }
+const char* ptts_debug_last_attention_kernel(void) { return g_last_attn_kernel; }
+
+int64_t ptts_debug_launch_counts(int32_t on, char* out, int64_t cap) {
+    static thread_local std::map<std::string, int64_t> census;
+    std::string s;
+    for (const auto& kv : census) s += kv.first + "=" + std::to_string(kv.second) + ";";
+    if (out && cap > 0) {
+        const size_t n = std::min<size_t>(s.size(), (size_t)cap - 1);
+        std::memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    census.clear();
+    g_launch_census = on ? &census : nullptr;
+    return (int64_t)s.size();
+}
 
 int ptts_plan_create(const char* path, const ptts_opts* opts, ptts_plan** out) {
     return guard([&] {
@@ -319,7 +334,7 @@ int ptts_profile_enable(ptts_model* h, int32_t on) {
         if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
         std::lock_guard<std::mutex> lock(h->m->mu);
         h->m->prof.on = on != 0;
-        h->m->prof.used = 0; h->m->prof.bytes = 0; h->m->prof.launches = 0;
+        h->m->prof.used = 0; h->m->prof.bytes = 0; h->m->prof.wbytes = 0; h->m->prof.launches = 0; h->m->prof.phases = false;
     });
 }
 
@@ -340,8 +355,16 @@ int ptts_profile_read(ptts_model* h, ptts_profile* out) {
         out->launches = m.prof.launches;
         out->total_ms = ms;
         out->algorithmic_bytes = m.prof.bytes;
+        out->weight_bytes = m.prof.wbytes;
+        if (m.prof.phases) {
+            PTTS_HIP(hipStreamSynchronize(m.stream2));
+            float t = 0;
+            PTTS_HIP(hipEventElapsedTime(&t, m.prof.phase[0], m.prof.phase[1])); out->prefill_ms = t;
+            PTTS_HIP(hipEventElapsedTime(&t, m.prof.phase[1], m.prof.phase[2])); out->ar_loop_ms = t;
+            PTTS_HIP(hipEventElapsedTime(&t, m.prof.phase[3], m.prof.phase[4])); out->mimi_ms = t;
+        }
         snprintf(out->kernel, sizeof out->kernel, "%s", "k_skinny");
-        m.prof.used = 0; m.prof.bytes = 0; m.prof.launches = 0;
+        m.prof.used = 0; m.prof.bytes = 0; m.prof.wbytes = 0; m.prof.launches = 0; m.prof.phases = false;
     });
 }
 
@@ -486,7 +509,7 @@ int ptts_batch_read_kv(ptts_batch* hb, int32_t slot, int32_t layer, float* k, fl
     });
 }
 
-int ptts_decode_latents(ptts_model* h, const float* latents, int32_t n_utt, int32_t frames, float* pcm, float* mimi_latent) {
+int ptts_decode_stages(ptts_model* h, const float* latents, int32_t n_utt, int32_t frames, float* pcm, float* mimi_latent, float* transformer_out) {
     return guard([&] {
         if (!h || !h->m) throw Error(PTTS_EINVAL, "native: model is not fully initialized");
         if (!latents) throw Error(PTTS_EINVAL, "native: latent tensor is nil");
@@ -496,14 +519,41 @@ int ptts_decode_latents(ptts_model* h, const float* latents, int32_t n_utt, int3
         m.use_device();
         const Desc& d = m.d;
         size_t nl = (size_t)n_utt * frames * d.ldim, np = (size_t)n_utt * frames * d.samples_per_frame, nm = (size_t)n_utt * d.mimi_dim * frames;
-        DevBuf& io = m.work(8, (nl + np + nm) * sizeof(float));
+        size_t nx = transformer_out ? (size_t)n_utt * frames * d.up_stride * d.mimi_dim : 0;
+        DevBuf& io = m.work(8, (nl + np + nm + nx) * sizeof(float));
         float* dl = io.as<float>();
         float* dp = dl + nl;
         float* dm = dp + np;
+        float* dx = dm + nm;
         PTTS_HIP(hipMemcpyAsync(dl, latents, nl * sizeof(float), hipMemcpyHostToDevice, m.stream));
-        mimi_decode(m, dl, (int64_t)frames * d.ldim, n_utt, frames, dp, mimi_latent ? dm : nullptr);
+        mimi_decode(m, dl, (int64_t)frames * d.ldim, n_utt, frames, dp, mimi_latent ? dm : nullptr, transformer_out ? dx : nullptr);
         if (pcm) PTTS_HIP(hipMemcpyAsync(pcm, dp, np * sizeof(float), hipMemcpyDeviceToHost, m.stream));
         if (mimi_latent) PTTS_HIP(hipMemcpyAsync(mimi_latent, dm, nm * sizeof(float), hipMemcpyDeviceToHost, m.stream));
+        if (transformer_out) PTTS_HIP(hipMemcpyAsync(transformer_out, dx, nx * sizeof(float), hipMemcpyDeviceToHost, m.stream));
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
+int ptts_decode_latents(ptts_model* h, const float* latents, int32_t n_utt, int32_t frames, float* pcm, float* mimi_latent) {
+    return ptts_decode_stages(h, latents, n_utt, frames, pcm, mimi_latent, nullptr);
+}
+
+int ptts_noise_rows(ptts_model* h, uint64_t seed, float temperature, int32_t rows, float* out) {
+    return guard([&] {
+        if (!h || !h->m || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        if (rows <= 0) throw Error(PTTS_EINVAL, "native: invalid gaussian noise shape");
+        Model& m = *h->m;
+        std::lock_guard<std::mutex> lock(m.mu);
+        m.use_device();
+        const int ld = m.d.ldim;
+        if (ld % 4) throw Error(PTTS_EINVAL, "ptts-hip: the device noise draw needs a latent width that is a multiple of 4");
+        NoiseSpec sp{seed, temperature > 0.0f ? std::sqrt(temperature) : 0.0f, rows};
+        DevBuf& sb = m.work(12, sizeof sp);
+        DevBuf& ob = m.work(8, (size_t)rows * ld * sizeof(float));
+        PTTS_HIP(hipMemcpyAsync(sb.p, &sp, sizeof sp, hipMemcpyHostToDevice, m.stream));
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+        launch_noise_fill(sb.as<NoiseSpec>(), 1, rows, ob.as<float>(), (int64_t)rows * ld, ld, m.stream);
+        PTTS_HIP(hipMemcpyAsync(out, ob.p, (size_t)rows * ld * sizeof(float), hipMemcpyDeviceToHost, m.stream));
         PTTS_HIP(hipStreamSynchronize(m.stream));
     });
 }
@@ -805,6 +855,16 @@ int ptts_op_attention_positions(const float* q, const float* k, const float* v, 
         a.context = (int)context;
         a.out = dout.as<float>(); a.out_ld = HD;
         a.rows = (int)(b * h * tq); a.heads = 1; a.max_keys = (int)tk;
+        // Self-attention over a whole sequence with a context window -- positions 0..T-1 on both sides, every slot valid: the
+        // call shape of mimiTransformerLayer.selfAttention (mimi.go:365-441).  Implicit positions and segments, so that the
+        // launch takes the Mimi decoder's own kernel (k_attn_window) and the reference's context-window tests exercise it.
+        bool plain_window = context > 0 && tq == tk;
+        for (int64_t i = 0; i < tq && plain_window; i++) plain_window = posq[i] == i && posk[i] == i;
+        if (plain_window) {
+            a.row_seg = nullptr; a.row_pos = nullptr;
+            a.rows_per_seg = (int)tq;
+            a.max_keys = (int)std::min<int64_t>(tk, context);
+        }
         launch_attention(a, nullptr);
         PTTS_HIP(hipDeviceSynchronize());
         std::vector<float> op((size_t)b * h * tq * HD);

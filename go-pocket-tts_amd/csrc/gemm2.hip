@@ -211,6 +211,7 @@ static void launch_bn(const GemmArgs& a, hipStream_t stream) {
 }
 
 void launch_gemm2(const GemmArgs& a, hipStream_t stream) {
+    note_launch("k_gemm2");
     if (a.N > 64) launch_bn<128>(a, stream);
     else if (a.N > 32) launch_bn<64>(a, stream);
     else launch_bn<32>(a, stream);

@@ -259,6 +259,7 @@ static void launch3_bn(const GemmArgs& a, hipStream_t stream) {
 // Measured on MI355X (tools/microbench_gemm.py, B=64 Mimi shapes, bf16 weights): 256 columns per wave halve the activation
 // loads per MFMA and win from N = 512 up (K = 512: +7..17 %, K >= 1024: +21..29 %); at N = 256 the two are level.
 void launch_gemm3(const GemmArgs& a, hipStream_t stream) {
+    note_launch(a.rope_cos ? "k_gemm3+rope" : a.kslice ? "k_gemm3+splitk" : "k_gemm3");
     const bool wide = g_gemm3_cfg == 4 || (g_gemm3_cfg == 0 && a.N >= 512 && a.M >= 16384);
     // few row panels (the prompt prefill: ~1600 rows): 128-column blocks would cover under 80 % of the CUs -- halve the block's columns
     const bool narrow = g_gemm3_cfg == 0 && a.M < 16384 && ((a.M + 127) / 128) * ((a.N + 127) / 128) * (a.kslice ? (a.K + a.kslice - 1) / a.kslice : 1) < 200;

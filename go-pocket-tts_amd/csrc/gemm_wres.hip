@@ -169,6 +169,7 @@ bool gemm_wres_supported(const GemmArgs& a) { return wres_shape(a) != 0; }
 void launch_gemm_wres(const GemmArgs& a, hipStream_t stream) {
     static const int cus = [] { int dev = 0, n = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int per_xcd = std::max(1, cus / 8);
+    note_launch(wres_shape(a) == 1 ? "k_gemm_wres<256,256>" : "k_gemm_wres<128,512>");
     if (wres_shape(a) == 1) {
         const int npan = (a.M + 31) / 32;
         const int rgl = std::max(1, std::min(per_xcd, (npan + 8 * WR_NW - 1) / (8 * WR_NW)));   // one block per CU at most

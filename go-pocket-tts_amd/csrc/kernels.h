@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <map>
+#include <string>
 
 namespace ptts {
 
@@ -157,6 +159,11 @@ struct AttnArgs {
     // [rag_off[s], rag_off[s+1]) at positions rag_pos0[s] + i; rows_per_seg is then the longest segment
     const int32_t* rag_off = nullptr; const int32_t* rag_pos0 = nullptr; int rag_segs = 0;
 };
+extern thread_local const char* g_last_attn_kernel;
+// Launch census for parity tests (ptts_debug_launch_counts): while switched on for the calling thread, every launcher notes the
+// kernel it picked, so a test can assert that the path it means to check is the one that ran.  Off: one thread-local load.
+extern thread_local std::map<std::string, int64_t>* g_launch_census;
+inline void note_launch(const char* kernel) { if (g_launch_census) (*g_launch_census)[kernel]++; }
 void launch_attention(const AttnArgs& a, hipStream_t stream);   // picks k_attn_step for the fused AR step when the cache fits one burst
 bool attn_step_supported(const AttnArgs& a);
 void launch_attn_step(const AttnArgs& a, hipStream_t stream);
@@ -240,6 +247,10 @@ void launch_step_begin(const StepState& s, const float* latents, int64_t lat_str
 // stores the decoded frame, applies EOS logic, advances kv_len/step
 void launch_step_finish(const StepState& s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,
                         int64_t lat_stride, hipStream_t stream);
+// device draw of the sampling noise (flow_lm.go:386-408): slot b gets rows [0, spec[b].rows) of out + b * out_stride as
+// N(0,1) * spec[b].sigma, a function of (spec[b].seed, row, element) only; rows == 0 leaves the slot untouched.  ldim % 4 == 0.
+struct NoiseSpec { uint64_t seed; float sigma; int32_t rows; };
+void launch_noise_fill(const NoiseSpec* spec_dev, int n_slots, int max_rows, float* out, int64_t out_stride, int ldim, hipStream_t stream);
 void launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 void launch_add_i32(int32_t* p, const int32_t* inc, int n, hipStream_t stream);
 

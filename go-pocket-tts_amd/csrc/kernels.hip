@@ -152,6 +152,7 @@ void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (wres && force != 2 && gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
     if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
+    note_launch("k_gemm");
     int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;
     int w_vec = a.w_bf16 ? ((reinterpret_cast<uintptr_t>(a.W) & 7) == 0 && a.ldw % 4 == 0) : (aligned16(a.W) && a.ldw % 4 == 0);
     dim3 grid((a.N + GN - 1) / GN, (a.M + GM - 1) / GM);
@@ -451,10 +452,15 @@ __global__ __launch_bounds__(256) void k_attention(AttnArgs a) {
     }
 }
 
+thread_local std::map<std::string, int64_t>* g_launch_census = nullptr;
+thread_local const char* g_last_attn_kernel = "";   // which kernel the calling thread's last launch_attention picked (parity tests assert it)
+
 void launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (a.rows <= 0) return;
-    if (attn_step_supported(a)) { launch_attn_step(a, stream); return; }
-    if (attn_window_supported(a)) { launch_attn_window(a, stream); return; }
+    if (attn_step_supported(a)) { g_last_attn_kernel = "k_attn_step"; launch_attn_step(a, stream); return; }
+    if (attn_window_supported(a)) { g_last_attn_kernel = a.rag_off ? "k_attn_window<ragged>" : "k_attn_window"; launch_attn_window(a, stream); return; }
+    g_last_attn_kernel = "k_attention";
+    note_launch("k_attention");
     const int wpq = a.fused_step ? 4 : (a.rows * a.heads < 2048 ? 4 : 1);
     const int qpb = 4 / wpq;
     size_t lds = ((size_t)qpb * a.max_keys + (size_t)qpb * wpq * 64 + 64) * sizeof(float);
@@ -792,6 +798,50 @@ void launch_step_begin(const StepState& s, const float* latents, int64_t lat_str
         hipLaunchKernelGGL(k_step_begin<false>, grid, dim3(256), 0, stream, s, latents, lat_stride, bos, noise, noise_stride, ldim, in32, x0, w_in,
                            lin ? lin->b_in : nullptr, lin ? lin->d_in : 0, lin ? lin->x : nullptr, lin ? lin->w_pj : nullptr,
                            lin ? lin->b_pj : nullptr, lin ? lin->d_pj : 0, lin ? lin->fx : nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sampling noise (FlowLM.makeGaussianNoise, flow_lm.go:386-408): N(0,1) * sqrt(max(temperature, 0)) per (utterance, step, latent
+// element).  The reference draws from a math/rand stream seeded with the wall clock when the runtime is created
+// (runtime_native_safetensors.go:27-32), i.e. it promises a distribution, not a sequence; here the draw is counter-based --
+// Philox-4x32-10 keyed by the request's seed, counter = (step, element quad) -- so that a (seed, step) pair names its noise row
+// whatever the batch composition, and Box-Muller turns each 4 x 32 bits into 4 normals.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0, n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1; c[3] = (uint32_t)p0; c[0] = n0; c[2] = n2;
+}
+__global__ void k_noise_fill(const NoiseSpec* spec, float* out, int64_t out_stride, int ldim) {
+    const NoiseSpec sp = spec[blockIdx.y];
+    const int quads = ldim / 4;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= sp.rows * quads) return;
+    const int step = i / quads, qd = i % quads;
+    uint32_t c[4] = {(uint32_t)step, (uint32_t)qd, 0u, 0u};
+    uint32_t k0 = (uint32_t)sp.seed, k1 = (uint32_t)(sp.seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    float v[4];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const float u1 = ((float)(c[2 * h] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1): 24 bits, never 0
+        const float u2 = ((float)(c[2 * h + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float r = sqrtf(-2.0f * logf(u1));
+        float sn, cs;
+        sincosf(6.28318530717958647692f * u2, &sn, &cs);
+        v[2 * h] = r * cs * sp.sigma;
+        v[2 * h + 1] = r * sn * sp.sigma;
+    }
+    *reinterpret_cast<float4*>(out + (int64_t)blockIdx.y * out_stride + (int64_t)step * ldim + qd * 4) = make_float4(v[0], v[1], v[2], v[3]);
+}
+void launch_noise_fill(const NoiseSpec* spec_dev, int n_slots, int max_rows, float* out, int64_t out_stride, int ldim, hipStream_t stream) {
+    if (n_slots <= 0 || max_rows <= 0) return;
+    const int per = max_rows * (ldim / 4);
+    hipLaunchKernelGGL(k_noise_fill, dim3((per + 255) / 256, n_slots), dim3(256), 0, stream, spec_dev, out, out_stride, ldim);
 }
 
 __global__ void k_step_finish(StepState s, const float* frame, const float* eos_logit, int ldim, int b, float* latents,

@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void k_layernorm_reg(LnArgs a) {
 }
 
 void launch_layernorm(const LnArgs& a, hipStream_t stream) {
+    note_launch("k_layernorm");
     if (a.rows <= 0) return;
     bool reg = a.d % 4 == 0 && a.d <= 1024 && a.xmap.ld % 4 == 0 && a.xmap.batch_stride % 4 == 0 && a.ldy % 4 == 0 && aligned16(a.x) &&
                (!a.y || aligned16(a.y)) && (!a.shift || (a.ldmod % 4 == 0 && aligned16(a.shift) && aligned16(a.scale))) &&

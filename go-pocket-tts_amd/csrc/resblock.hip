@@ -354,6 +354,7 @@ static void launch_rb(const ResArgs& a, hipStream_t stream) {
 }
 
 void launch_resblock(const ResArgs& a, hipStream_t stream) {
+    note_launch(a.final_conv ? "k_resblock+final" : "k_resblock");
     if (a.C == 64) launch_rb<64, 32, 8>(a, stream);    // 128-row tiles, ~50 KB of LDS: three blocks per CU
     else launch_rb<128, 64, 4>(a, stream);             // 64-row tiles, same footprint
 }

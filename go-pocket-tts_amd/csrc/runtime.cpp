@@ -75,6 +75,7 @@ static void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
 Model::~Model() {
     if (upload.base) (void)hipHostFree(upload.base);
     for (hipEvent_t e : prof.ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : prof.phase) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : events) (void)hipEventDestroy(e);
     if (stream2) (void)hipStreamDestroy(stream2);
 
@@ -95,6 +96,7 @@ Model* model_open(Plan* plan, void* device_arena, int fill) {
     m->d = plan->desc;
     m->opts = plan->opts;
     m->device = plan->opts.device;
+    m->noise_state = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)m.get();
     m->use_device();
     {
         int lo = 0, hi = 0;   // numerically lower = higher priority
@@ -127,6 +129,7 @@ Model* model_share(Model& base) {
     m->d = base.d;
     m->opts = base.opts;
     m->device = base.device;
+    m->noise_state = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)m.get();
     m->use_device();
     int lo = 0, hi = 0;
     PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -478,6 +481,7 @@ static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = Skinny
         p.used += 2;
         p.launches++;
         p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 * (1 + fu.psplit) + (double)g.M * g.N * 4 * (splitk > 1 ? splitk : 1);
+        p.wbytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4);
     }
 }
 
@@ -756,7 +760,7 @@ static void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
 // frames [f0, f1) of every utterance; lat: device [B][*][ldim] with lat_bstride elements between utterances;
 // pcm: device [B][T * samples_per_frame]; mimi_latent (optional): [B][C][T] (whole range only)
 void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
-                const PcmRow* pcm_rows, bool* rows_used) {
+                const PcmRow* pcm_rows, bool* rows_used, float* xformer_out) {
     if (rows_used) *rows_used = false;
     const Desc& d = m.d;
     const int B = w.B, T = w.T, C = d.mimi_dim, S = d.up_stride, T1 = T * S, F = d.mimi_ffn, P0 = w.P0;
@@ -814,6 +818,9 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         g2.R = upx; g2.epi = L.ls2 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; g2.scale = m.at<float>(L.ls2);
         launch_gemm(g2, s);
     }
+    if (xformer_out)   // staged parity check: the residual stream after the last layer, [B][T1][C] (rows of this range)
+        PTTS_HIP(hipMemcpy2DAsync(xformer_out + (size_t)t0 * C, (size_t)T1 * C * sizeof(float), upx, (size_t)up_bs * sizeof(float), (size_t)CT * C * sizeof(float),
+                                  (size_t)B, hipMemcpyDeviceToDevice, s));
     // SEANet decoder (mimi.go:740-788): causal convs as GEMMs over contiguous channels-last windows
     int r0 = t0, rn = CT;   // row range at the current rate
     {
@@ -880,7 +887,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
     launch_conv_final(w.uo[2], w.Ps[3], m.at<float>(d.final_w), m.at<float>(d.final_b), B, w.Ls[3], r0, r0 + rn, d.sea_ch[3], d.final_k, 0, pcm, s);
 }
 
-void mimi_decode(Model& m, const float* lat, int64_t lat_bstride, int B, int T, float* pcm, float* mimi_latent) {
+void mimi_decode(Model& m, const float* lat, int64_t lat_bstride, int B, int T, float* pcm, float* mimi_latent, float* xformer_out) {
     if (B <= 0 || T <= 0) return;
     if ((int64_t)T * m.d.up_stride > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)T * m.d.up_stride));
     // bound the workspace: ~2.7 MB of f32 activations per latent frame at the reference shapes
@@ -894,7 +901,8 @@ void mimi_decode(Model& m, const float* lat, int64_t lat_bstride, int B, int T, 
         MimiWs w;
         mimi_setup(m, w, nb, T);
         mimi_range(m, w, lat + (int64_t)b0 * lat_bstride, lat_bstride, 0, T, pcm + (int64_t)b0 * spu,
-                   mimi_latent ? mimi_latent + (int64_t)b0 * d.mimi_dim * T : nullptr, m.stream);
+                   mimi_latent ? mimi_latent + (int64_t)b0 * d.mimi_dim * T : nullptr, m.stream, nullptr, nullptr,
+                   xformer_out ? xformer_out + (int64_t)b0 * T * d.up_stride * d.mimi_dim : nullptr);
     }
 }
 
@@ -929,11 +937,17 @@ void* result_alloc(size_t bytes) {
     void* p = nullptr;
     if (hipHostMalloc(&p, sz, hipHostMallocDefault) != hipSuccess || !p) {
         (void)hipGetLastError();
-        return malloc(sz);   // still a valid result buffer, just a slower copy
+        return malloc(sz);   // still a valid result buffer for the copy path (result_is_pinned() says no: never handed to a kernel)
     }
     std::lock_guard<std::mutex> lock(pp.mu);
     pp.owned[p] = sz;
     return p;
+}
+
+bool result_is_pinned(const void* p) {
+    PinnedPool& pp = pool();
+    std::lock_guard<std::mutex> lock(pp.mu);
+    return p && pp.owned.count(const_cast<void*>(p)) != 0;
 }
 
 void result_free(void* p) {
@@ -1108,11 +1122,25 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         flush();
     }
     mark("setup");
+    auto phase = [&](int i, hipStream_t st) {   // measurement pass only (ptts_profile_enable): device time of the call's phases
+        if (!m.prof.on) return;
+        if (!m.prof.phase[i]) PTTS_HIP(hipEventCreate(&m.prof.phase[i]));
+        PTTS_HIP(hipEventRecord(m.prof.phase[i], st));
+    };
+    m.prof.phases = false;
+    phase(0, s);
     batch_prompt(b, rows.as<float>(), row_off.data());
+    phase(1, s);
     mark("prefill");
-    // injected sampling noise (flow_lm.go:283-288)
-    bool any_noise = false;
-    for (int i = 0; i < B; i++) any_noise |= reqs[idx[i]].noise != nullptr;
+    // sampling noise (flow_lm.go:283-288,386-408): injected rows as they are; otherwise N(0,1) * sqrt(temperature) drawn on the
+    // device per (seed, step); temperature <= 0: zeros.  All of it is resident before the first step, so the AR loop (plain
+    // launches or graph replay) just reads row `step` of its slot.
+    bool any_noise = false, any_draw = false;
+    for (int i = 0; i < B; i++) {
+        const ptts_request& r = reqs[idx[i]];
+        any_noise |= r.noise != nullptr || r.temperature > 0.0f;
+        any_draw |= r.noise == nullptr && r.temperature > 0.0f;
+    }
     b.has_noise = any_noise;
     if (any_noise) {
         size_t n = (size_t)B * b.max_steps * ld;
@@ -1120,6 +1148,18 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         PTTS_HIP(hipMemsetAsync(b.noise.p, 0, n * sizeof(float), s));
         for (int i = 0; i < B; i++)
             if (reqs[idx[i]].noise) h2d(b.noise.as<float>() + (size_t)i * b.max_steps * ld, reqs[idx[i]].noise, (size_t)ms[i] * ld * sizeof(float), s);
+        if (any_draw) {
+            if (ld % 4) throw Error(PTTS_EINVAL, "ptts-hip: the device noise draw needs a latent width that is a multiple of 4");
+            std::vector<NoiseSpec> spec((size_t)B);
+            for (int i = 0; i < B; i++) {
+                const ptts_request& r = reqs[idx[i]];
+                const bool draw = r.noise == nullptr && r.temperature > 0.0f;
+                spec[(size_t)i] = NoiseSpec{draw ? (r.noise_seed ? r.noise_seed : m.next_noise_seed()) : 0, draw ? std::sqrt(r.temperature) : 0.0f, draw ? ms[i] : 0};
+            }
+            DevBuf& sb = m.work(12, spec.size() * sizeof(NoiseSpec));
+            h2d(sb.p, spec.data(), spec.size() * sizeof(NoiseSpec), s);
+            launch_noise_fill(sb.as<NoiseSpec>(), B, ms_max, b.noise.as<float>(), (int64_t)b.max_steps * ld, ld, s);
+        }
     }
     m.tcomb_for(lsd);
     // PTTS_GRAPH=0/1 overrides the option (A/B measurement, tools/eager_vs_graph.py)
@@ -1158,6 +1198,20 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     std::vector<std::unique_ptr<StreamChunk>> stream_chunks;
     std::vector<int32_t*> stream_nf;
     DevBuf* stream_s16 = nullptr;
+    // Error path: a throw below may leave copies, decoder launches and host functions queued on the two streams that still read
+    // `cancelled`, `stream_chunks`, `stream_host` (declared above, destroyed after this guard): drain both streams first, then
+    // give the streaming buffers back.  Dismissed on the normal path, which does the same things in order.
+    struct Unwind {
+        Model& m; std::vector<void*>& host; std::vector<int32_t*>& nf; bool armed = true;
+        ~Unwind() {
+            if (!armed) return;
+            (void)hipStreamSynchronize(m.stream2);
+            (void)hipStreamSynchronize(m.stream);
+            for (int32_t* p : nf) (void)hipHostFree(p);
+            nf.clear();
+            for (void*& p : host) { result_free(p); p = nullptr; }
+        }
+    } unwind{m, stream_host, stream_nf};
     if (streaming) {
         chunk = 1 << 30;
         bool any_s16 = false;
@@ -1257,6 +1311,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             if (*b.n_active_pinned <= 0) break;
         }
     }
+    phase(2, s);
     mark("ar loop");
     // n_frames and eos_step sit side by side in the state block: one copy into page-locked memory, one wait
     PTTS_HIP(hipMemcpyAsync(b.n_active_pinned + 1, b.st.n_frames, (size_t)2 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -1321,14 +1376,23 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
                 if (!host_dst[(size_t)i]) continue;   // reported as PTTS_ENOMEM by finish_rows
                 rows[i] = PcmRow{host_dst[(size_t)i], (int32_t)std::min<int64_t>(ns, INT32_MAX), s16 ? 1 : 0};
             }
-            DevBuf& rb = m.work(11, (size_t)B * sizeof(PcmRow));
-            PTTS_HIP(hipMemcpyAsync(rb.p, rows, (size_t)B * sizeof(PcmRow), hipMemcpyHostToDevice, s));   // page-locked source: no wait needed
-            d_rows = rb.as<PcmRow>();
+            // a kernel may only store into page-locked memory: if the pool had to fall back to pageable blocks (hipHostMalloc
+            // failed), the whole batch takes the device buffer + copy path instead
+            bool all_pinned = true;
+            for (int i = 0; i < B; i++) all_pinned &= !host_dst[(size_t)i] || result_is_pinned(host_dst[(size_t)i]);
+            if (all_pinned) {
+                DevBuf& rb = m.work(11, (size_t)B * sizeof(PcmRow));
+                PTTS_HIP(hipMemcpyAsync(rb.p, rows, (size_t)B * sizeof(PcmRow), hipMemcpyHostToDevice, s));   // page-locked source: no wait needed
+                d_rows = rb.as<PcmRow>();
+            }
         }
         pcm_rows = d_rows; rows_used = &direct_done;
+        if (m.prof.on) { PTTS_HIP(hipStreamWaitEvent(m.stream2, m.prof.phase[2], 0)); phase(3, m.stream2); }
         decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
         pcm_rows = nullptr; rows_used = nullptr;
         emit_upto(std::min(steps_run, Tmax));
+        phase(4, m.stream2);
+        m.prof.phases = m.prof.on && f_done > 0;
         PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int32_t* p : stream_nf) (void)hipHostFree(p);
         stream_nf.clear();
@@ -1344,12 +1408,16 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         for (int i = 0; i < B; i++) fail_req(res[idx[i]], PTTS_ECANCELLED);
     }
     for (void* p : stream_host) result_free(p);   // buffers of cancelled / failed streaming requests
+    unwind.armed = false;
 }
 
 std::string request_error(const Desc& d, const ptts_request& q) {   // the argument checks of GenerateAudio (runtime_native_safetensors.go:52-119)
     if (!q.tokens || q.n_tokens <= 0) return "generate: token slice must not be empty";
     if ((q.voice_embedding != nullptr) + (q.voice_caches != nullptr) + (q.voice != nullptr) > 1) return "generate: voice embedding and voice model state are mutually exclusive";
     if (q.voice_caches && (!q.voice_cache_steps || !q.voice_offsets)) return "generate: load voice model state: missing cache steps/offsets";
+    if (q.noise && q.noise_rows > 0 && q.noise_rows < resolve_max_steps(q))
+        return strfmt("generate: injected noise has %d rows, the step budget is %d", q.noise_rows, resolve_max_steps(q));
+    if (std::isnan(q.temperature)) return "generate: temperature is NaN";
     for (int64_t t = 0; t < q.n_tokens; t++)
         if (q.tokens[t] < 0 || q.tokens[t] >= d.n_bins)
             return strfmt("generate: text embeddings: native: token id %lld (%lld) out of range [0,%d)", (long long)t, (long long)q.tokens[t], d.n_bins);

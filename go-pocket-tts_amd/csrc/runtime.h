@@ -37,8 +37,10 @@ struct Prof {   // bench.py measurement hook (ptts_profile_*)
     bool on = false;
     std::vector<hipEvent_t> ev;
     size_t used = 0;
-    double bytes = 0;
+    double bytes = 0, wbytes = 0;
     int64_t launches = 0;
+    hipEvent_t phase[5] = {};   // setup | prefill | AR loop on the model's stream; Mimi start | end on the decoder's stream
+    bool phases = false;
 };
 
 // page-locked staging for the small host->device uploads of one generate call (runtime.cpp: h2d)
@@ -71,6 +73,16 @@ struct Model {
         return *ws[i];
     }
     void use_device() const { PTTS_HIP(hipSetDevice(device)); }
+    // seeds of requests that name none (noise_seed == 0): a splitmix64 stream seeded with the clock when the model is opened
+    // (the reference seeds its generator the same way, runtime_native_safetensors.go:27-32); never 0
+    uint64_t noise_state = 0;
+    uint64_t next_noise_seed() {
+        uint64_t z = (noise_state += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        return z ? z : 1;
+    }
     const float* tcomb_for(int lsd_steps);
     void compute_tcomb(float s, float t, float* dst /* device [flow_dim] */);
 };
@@ -125,6 +137,7 @@ struct Batch {
 // 64 x 10 s batch; pinned: ~50 GB/s).  Pinning is slow, so freed buffers go back to a process-wide pool.
 void* result_alloc(size_t bytes);
 void result_free(void* p);   // accepts pool blocks and plain malloc'ed pointers
+bool result_is_pinned(const void* p);   // false for the pageable fallback blocks: those must not be written by a kernel
 
 // a voice model state resident in HBM: K and V per layer as [H][offset][hd] in the cache dtype
 struct Voice {
@@ -149,7 +162,7 @@ void mimi_setup(Model& m, MimiWs& w, int B, int T);
 // pcm_rows (device array of B PcmRow, whole range only): the fused final block writes every utterance's samples straight to its
 // row (page-locked host memory) instead of pcm; *rows_used says whether that path was taken (false: pcm holds the samples)
 void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
-                const PcmRow* pcm_rows = nullptr, bool* rows_used = nullptr);
+                const PcmRow* pcm_rows = nullptr, bool* rows_used = nullptr, float* xformer_out = nullptr);
 
 Model* model_open(Plan* plan, void* device_arena, int fill);
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);
@@ -162,7 +175,8 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 // whether it did (false: the caller launches k_step_finish)
 bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = false);
 void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
-void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev);
+// xformer_out (optional, staged parity checks): the decoder transformer's output rows [B][T * up_stride][mimi_dim]
+void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev, float* xformer_out = nullptr);
 Model* model_share(Model& base);   // another engine over base's weight arena (base must outlive it)
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
 std::string request_error(const Desc& d, const ptts_request& q);   // empty: the request is well formed

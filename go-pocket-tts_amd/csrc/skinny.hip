@@ -499,6 +499,7 @@ static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float*
 
 void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return;
+    note_launch("k_skinny");
     dim3 grid((a.N + 63) / 64, (a.M + 15) / 16, splitk);
     if (a.w_bf16) launch_w<true>(a, fu, splitk, partial, grid, stream);
     else launch_w<false>(a, fu, splitk, partial, grid, stream);

@@ -60,12 +60,13 @@ class _Request(C.Structure):
                 ("frames_after_eos", C.c_int32), ("voice_embedding", _FP), ("voice_frames", C.c_int64),
                 ("voice_caches", C.POINTER(_FP)), ("voice_cache_steps", _IP), ("voice_offsets", _IP), ("noise", _FP),
                 ("step_callback", _STEP_CB), ("callback_user", C.c_void_p), ("cancel", C.POINTER(C.c_int32)),
-                ("want_latents", C.c_int32), ("pcm_format", C.c_int32), ("voice", C.c_void_p), ("reserved", C.c_int32 * 4),
+                ("want_latents", C.c_int32), ("pcm_format", C.c_int32), ("voice", C.c_void_p), ("noise_seed", C.c_uint64), ("noise_rows", C.c_int32), ("reserved", C.c_int32 * 1),
                 ("pcm_callback", _PCM_CB), ("pcm_user", C.c_void_p), ("stream_frames", C.c_int32), ("reserved2", C.c_int32 * 3)]
 
 
 class _Profile(C.Structure):
-    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double), ("kernel", C.c_char * 64)]
+    _fields_ = [("launches", C.c_int64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double), ("kernel", C.c_char * 64),
+                ("weight_bytes", C.c_double), ("prefill_ms", C.c_double), ("ar_loop_ms", C.c_double), ("mimi_ms", C.c_double)]
 
 
 class _Result(C.Structure):
@@ -88,7 +89,7 @@ ABI_SYMBOLS = [
     "ptts_plan_create", "ptts_plan_create_bytes", "ptts_plan_arena_bytes", "ptts_model_open_planned", "ptts_plan_free",
     "ptts_generate", "ptts_free_result", "ptts_text_embeddings", "ptts_batch_new", "ptts_batch_free", "ptts_batch_reset",
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
-    "ptts_decode_latents", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
+    "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_noise_rows", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
@@ -147,6 +148,11 @@ def lib():
         L.ptts_batch_offsets.argtypes = [C.c_void_p, _IP]
         L.ptts_batch_read_kv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, _FP]
         L.ptts_decode_latents.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP]
+        L.ptts_decode_stages.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP, _FP]
+        L.ptts_noise_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, _FP]
+        L.ptts_debug_last_attention_kernel.restype = C.c_char_p
+        L.ptts_debug_launch_counts.restype = C.c_int64
+        L.ptts_debug_launch_counts.argtypes = [C.c_int32, C.c_char_p, C.c_int64]
         L.ptts_flow_direction.argtypes = [C.c_void_p, _FP, C.c_float, C.c_float, _FP, C.c_int32, _FP]
         L.ptts_voice_create.argtypes = [C.c_void_p, C.POINTER(_FP), _IP, _IP, C.POINTER(C.c_void_p)]
         L.ptts_voice_free.argtypes = [C.c_void_p]
@@ -212,6 +218,7 @@ class RuntimeGenerateConfig:
     device_voice: Optional["DeviceVoice"] = None   # a VoiceModelState already uploaded with Model.upload_voice
     step_callback: Optional[Callable[[int, int], None]] = None
     noise: Optional[np.ndarray] = None
+    noise_seed: int = 0   # device draw (temperature > 0, no injected noise): 0 = a fresh stream per request, like the reference's clock-seeded rng
     cancel: Optional[np.ndarray] = None  # int32[1]; nonzero = cancelled (the ctx of GenerateAudio)
     want_latents: bool = False
     pcm16: bool = False   # PCM egress on the device: GenerateResult.pcm is int16 = audio.WritePCM16Samples (wav_stream.go:43-54)
@@ -361,7 +368,8 @@ class Model:
         p = _Profile()
         _check(lib().ptts_profile_read(self.h, C.byref(p)))
         return {"kernel": p.kernel.decode(), "launches": int(p.launches), "total_ms": float(p.total_ms),
-                "algorithmic_bytes": float(p.algorithmic_bytes)}
+                "algorithmic_bytes": float(p.algorithmic_bytes), "weight_bytes": float(p.weight_bytes),
+                "prefill_ms": float(p.prefill_ms), "ar_loop_ms": float(p.ar_loop_ms), "mimi_ms": float(p.mimi_ms)}
 
     def new_batch(self, n_slots: int, kv_capacity: int) -> "Batch":
         return Batch(self, n_slots, kv_capacity)
@@ -376,6 +384,25 @@ class Model:
         ml = np.empty((n, self.info.mimi_dim, fr), np.float32) if want_mimi_latent else None
         _check(lib().ptts_decode_latents(self.h, _fp(lat), n, fr, _fp(pcm), _fp(ml)))
         return (pcm, ml) if want_mimi_latent else pcm
+
+    def decode_stages(self, latents):
+        """decode_latents plus the decoder transformer's output rows [n, 16 frames, mimi_dim] (mimi.go:733-748):
+        returns (pcm, mimi_latent, transformer_out)."""
+        lat = _f32(latents)
+        if lat.ndim == 2:
+            lat = lat[None]
+        n, fr, _ = lat.shape
+        pcm = np.empty((n, fr * self.info.samples_per_frame), np.float32)
+        ml = np.empty((n, self.info.mimi_dim, fr), np.float32)
+        xf = np.empty((n, fr * self.info.steps_per_latent, self.info.mimi_dim), np.float32)
+        _check(lib().ptts_decode_stages(self.h, _fp(lat), n, fr, _fp(pcm), _fp(ml), _fp(xf)))
+        return pcm, ml, xf
+
+    def noise_rows(self, seed: int, temperature: float, rows: int) -> np.ndarray:
+        """The device draw of makeGaussianNoise (flow_lm.go:386-408) a request with (noise_seed, temperature) consumes."""
+        out = np.empty((rows, self.info.ldim), np.float32)
+        _check(lib().ptts_noise_rows(self.h, C.c_uint64(seed), C.c_float(temperature), rows, _fp(out)))
+        return out
 
     def flow_direction(self, c, s: float, t: float, x) -> np.ndarray:
         c = _f32(c).reshape(-1, self.info.d_model)
@@ -406,6 +433,8 @@ class Model:
             nz = _f32(cfg.noise).reshape(-1, self.info.ldim)
             keep.append(nz)
             r.noise = _fp(nz)
+            r.noise_rows = nz.shape[0]
+        r.noise_seed = int(cfg.noise_seed)
         if cfg.step_callback is not None:
             cb = _STEP_CB(lambda _u, s, m, f=cfg.step_callback: f(s, m))
             keep.append(cb)
@@ -655,6 +684,18 @@ def op_attention_positions(q, k, v, posq, posk, context: int) -> np.ndarray:
     out = np.empty((b, h, tq, d), np.float32)
     _check(lib().ptts_op_attention_positions(_fp(q), _fp(k), _fp(v), b, h, tq, tk, d, _ip(pq), _ip(pk), context, _fp(out)))
     return out
+
+
+def last_attention_kernel() -> str:
+    """Which kernel this thread's last attention launch used (ptts_debug_last_attention_kernel)."""
+    return lib().ptts_debug_last_attention_kernel().decode()
+
+
+def launch_counts(on: bool) -> dict:
+    """Kernel launches noted on this thread since the previous call ({kernel: count}); switches the census on / off."""
+    buf = C.create_string_buffer(4096)
+    lib().ptts_debug_launch_counts(1 if on else 0, buf, 4096)
+    return {k: int(v) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
 
 
 def op_conv1d_leftpad(x, w, bias=None) -> np.ndarray:

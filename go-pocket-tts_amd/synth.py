@@ -34,6 +34,7 @@ class SynthConfig:
     mimi_ffn: int = 2048
     n_filters: int = 64        # SEANet ladder 8f -> 4f -> 2f -> f -> 1
     input_linear_bias: bool = False
+    layer_scale: float = 0.01  # Mimi layer_scale_{1,2}; ~1 makes the decoder transformer's branches count in full
 
     @staticmethod
     def full() -> "SynthConfig":
@@ -155,8 +156,12 @@ def make_checkpoint(cfg: SynthConfig = SynthConfig(), seed: int = 1234) -> dict[
         lin(p + ".self_attn.out_proj", M, M, False)
         lin(p + ".linear1", cfg.mimi_ffn, M, False)
         lin(p + ".linear2", M, cfg.mimi_ffn, False)
-        t[p + ".layer_scale_1.scale"] = np.full(M, 0.01, np.float32)
-        t[p + ".layer_scale_2.scale"] = np.full(M, 0.01, np.float32)
+        if cfg.layer_scale == 0.01:
+            t[p + ".layer_scale_1.scale"] = np.full(M, 0.01, np.float32)
+            t[p + ".layer_scale_2.scale"] = np.full(M, 0.01, np.float32)
+        else:   # per-channel values around the requested scale (a uniform vector would hide a channel mix-up)
+            t[p + ".layer_scale_1.scale"] = (cfg.layer_scale * (1.0 + 0.25 * rng.uniform(-1, 1, M))).astype(np.float32)
+            t[p + ".layer_scale_2.scale"] = (cfg.layer_scale * (1.0 + 0.25 * rng.uniform(-1, 1, M))).astype(np.float32)
 
     def conv(name: str, oc: int, ic: int, k: int) -> None:
         t[name + ".weight"] = (rng.standard_normal((oc, ic, k)) / np.sqrt(ic * k)).astype(np.float32)

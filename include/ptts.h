@@ -104,7 +104,8 @@ typedef void (*ptts_pcm_callback)(void* user, int64_t sample_offset, int64_t n_s
 
 typedef struct ptts_request {
     const int64_t* tokens; int64_t n_tokens;          /* must be non-empty (:57-59) */
-    float   temperature;                              /* only validates `noise`: <=0 means zero noise (flow_lm.go:395-404) */
+    float   temperature;                              /* RuntimeGenerateConfig.Temperature: sampling noise = N(0,1) * sqrt(max(t, 0)), drawn on the
+                                                       * device per (noise_seed, step) when `noise` is NULL; <= 0: zero noise (flow_lm.go:386-408) */
     float   eos_threshold;                            /* isEOS = logit > threshold (flow_lm.go:281) */
     int32_t max_steps;                                /* <=0: estimated_max_steps, then EstimateMaxFrames (:61-67) */
     int32_t estimated_max_steps;
@@ -115,8 +116,9 @@ typedef struct ptts_request {
     const float* const* voice_caches;                           /* per layer [2,1,T,H,Dh] f32 (flow_transformer.go:451-552) */
     const int64_t* voice_cache_steps;                           /* per layer T */
     const int64_t* voice_offsets;                               /* per layer offset, 0 <= offset <= T */
-    /* sampling noise: [max_steps, ldim] = N(0,1)*sqrt(temperature) draws, one row per AR step,
-     * consumed as x0 of that step's LSD decode (flow_lm.go:283-288).  NULL = zeros. */
+    /* injected sampling noise (reproducible runs, parity tests): [noise_rows, ldim] = N(0,1)*sqrt(temperature) draws, one row
+     * per AR step, consumed as x0 of that step's LSD decode (flow_lm.go:283-288); replaces the device draw.  NULL: the library
+     * draws (temperature > 0) or uses zeros (temperature <= 0). */
     const float* noise;
     ptts_step_callback step_callback; void* callback_user;
     const volatile int32_t* cancel;                   /* polled between steps; nonzero -> PTTS_ECANCELLED */
@@ -126,7 +128,10 @@ typedef struct ptts_request {
      * The reference loads the voice file once per Synthesize call and rebuilds the FlowLM state from it for
      * every chunk (service.go:127,216-246, flow_lm.go:134-145); the device copy is that cached voice. */
     const ptts_voice* voice;
-    int32_t reserved[4];
+    uint64_t noise_seed;                              /* device draw: the stream of this request; 0 = a fresh one per request from the model's
+                                                       * own generator, seeded with the clock at open like the reference's (runtime_native_safetensors.go:27-32) */
+    int32_t noise_rows;                               /* rows behind `noise`; must cover the resolved step budget (0: not checked, the caller vouches) */
+    int32_t reserved[1];
     /* Frame-granular streaming (the /tts/stream path, server.go:354-396, at finer grain than the reference's per-chunk
      * PCMChunk): finished frame ranges are decoded while the AR loop is still running and handed over in order, each sample
      * exactly once, from a library thread; `samples` points into the buffer the result will own (float or int16 per
@@ -225,6 +230,8 @@ typedef struct ptts_profile {
     double  total_ms;            /* sum of the event-pair durations */
     double  algorithmic_bytes;   /* sum over launches of weights + activations in + out */
     char    kernel[64];
+    double  weight_bytes;        /* the weights-only part of algorithmic_bytes (each step linear's matrix once per launch) */
+    double  prefill_ms, ar_loop_ms, mimi_ms;   /* device time of the phases of the last ptts_generate call (HIP events on its streams) */
 } ptts_profile;
 int ptts_profile_enable(ptts_model* m, int32_t on);
 int ptts_profile_read(ptts_model* m, ptts_profile* out);   /* returns and resets the counters */
@@ -250,6 +257,14 @@ int  ptts_batch_read_kv(ptts_batch* b, int32_t slot, int32_t layer, float* k, fl
  * mimi_latent (optional) receives LatentToMimi's [n_utt, mimi_dim, frames] */
 int  ptts_decode_latents(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,
                          float* pcm, float* mimi_latent);
+/* The same with one more observation point: transformer_out (optional) receives the decoder transformer's output, i.e. the
+ * [n_utt, frames * steps_per_latent, mimi_dim] rows that MimiModel.DecodeFromLatent hands to the SEANet decoder after its
+ * mimiTransformerLayer loop (mimi.go:733-748) -- the staged check of a17 (window attention, RoPE, layer_scale). */
+int  ptts_decode_stages(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,
+                        float* pcm, float* mimi_latent, float* transformer_out);
+/* The device draw of FlowLM.makeGaussianNoise (flow_lm.go:386-408) for one request: out[rows, ldim] (host) receives exactly the
+ * rows ptts_generate would consume for (noise_seed = seed, temperature) -- so that a test can hand the same noise to a reference. */
+int  ptts_noise_rows(ptts_model* m, uint64_t seed, float temperature, int32_t rows, float* out);
 /* FlowLM.FlowDirection (flow_lm.go:302-308): c [n, d_model], x [n, ldim] -> out [n, ldim] */
 int  ptts_flow_direction(ptts_model* m, const float* c, float s, float t, const float* x, int32_t n, float* out);
 
@@ -279,6 +294,15 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
 
 /* audio.WritePCM16Samples on the device (internal/audio/wav_stream.go:43-54), without the byte packing */
 int ptts_op_pcm16(const float* samples, int64_t n, int16_t* out);
+
+/* name of the kernel the calling thread's last attention launch used ("k_attn_step", "k_attn_window", "k_attn_window<ragged>",
+ * "k_attention"): lets a parity test assert that it exercised the kernel it means to */
+const char* ptts_debug_last_attention_kernel(void);
+
+/* Launch census of the calling thread: writes "kernel=count;..." of the launches noted since the previous call (truncated to
+ * cap - 1 characters, returns the full length), clears it, and switches counting on (1) or off (0) from here on.  Calls that
+ * run their launches on the calling thread (every entry point except the dispatcher's) are covered. */
+int64_t ptts_debug_launch_counts(int32_t on, char* out, int64_t cap);
 
 const char* ptts_version(void);
 

@@ -185,7 +185,8 @@ class _PoRequest(C.Structure):
 
 class _PoResult(C.Structure):
     _fields_ = [("pcm", C.POINTER(C.c_float)), ("n_samples", C.c_int64),
-                ("latents", C.POINTER(C.c_float)), ("n_frames", C.c_int32), ("eos_step", C.c_int32)]
+                ("latents", C.POINTER(C.c_float)), ("n_frames", C.c_int32), ("eos_step", C.c_int32),
+                ("eos_logits", C.POINTER(C.c_float))]
 
 
 _FP = C.POINTER(C.c_float)
@@ -585,6 +586,18 @@ class OracleModel:
             raise ValueError("native: mimi decode failed")
         return pcm
 
+    def mimi_transformer(self, x) -> np.ndarray:
+        """Staged: upsample + decoder transformer layers (mimi.go:733-748), rows [16 T, mimi_dim]."""
+        x = _f32(x).reshape(self.mimi_dim, -1)
+        t = x.shape[1]
+        out = np.empty((16 * t, self.mimi_dim), np.float32)
+        if lib().po_mimi_transformer(C.c_void_p(self.h), _fp(x), C.c_int64(t), _fp(out)):
+            raise ValueError("native: mimi transformer failed")
+        return out
+
+    def debug_set_mimi_context(self, context: int) -> None:
+        lib().po_debug_set_mimi_context(C.c_void_p(self.h), C.c_int64(context))
+
     def generate(self, tokens, *, max_steps=0, eos_threshold=-4.0, lsd_steps=1, frames_after_eos=3,
                  voice_emb=None, voice_state=None, noise=None):
         """tts.Runtime.GenerateAudio (runtime_native_safetensors.go:52-238)."""
@@ -620,7 +633,8 @@ class OracleModel:
             raise ValueError(err.value.decode())
         pcm = np.ctypeslib.as_array(res.pcm, (res.n_samples,)).copy()
         lat = np.ctypeslib.as_array(res.latents, (res.n_frames, self.ldim)).copy()
-        out = {"pcm": pcm, "latents": lat, "n_frames": int(res.n_frames), "eos_step": int(res.eos_step)}
+        logits = np.ctypeslib.as_array(res.eos_logits, (res.n_frames,)).copy()
+        out = {"pcm": pcm, "latents": lat, "n_frames": int(res.n_frames), "eos_step": int(res.eos_step), "eos_logits": logits}
         lib().po_free_result(C.byref(res))
         return out
 

@@ -1245,6 +1245,20 @@ int64_t po_mimi_out_len(const po_model* m, int64_t t) { /* length bookkeeping of
     return len * m->final_conv.out_ch;
 }
 
+int po_mimi_transformer(const po_model* m, const float* xin, int64_t t, float* out) { /* mimi.go:733-748: upsample, [C,T] -> [T,C], layers */
+    int64_t len; int rc = 0;
+    float* x = convtr_stream(&m->upsample, xin, t, &len);
+    int64_t C = m->mimi_dim;
+    transpose2d(x, C, len, out);
+    for (int64_t i = 0; i < m->n_mimi_layers && rc == 0; i++) rc = mimi_layer(m, &m->mimi_layers[i], out, len);
+    free(x);
+    return rc;
+}
+
+void po_debug_set_mimi_context(po_model* m, int64_t context) {
+    for (int64_t i = 0; i < m->n_mimi_layers; i++) m->mimi_layers[i].context = context;
+}
+
 int po_mimi_decode(const po_model* m, const float* xin, int64_t t, float* pcm) { /* mimi.go:719-789 */
     int64_t len; int rc = 0;
     float* x = convtr_stream(&m->upsample, xin, t, &len);                     /* upsample */
@@ -1294,14 +1308,15 @@ int po_generate(const po_model* m, const po_request* rq, po_result* res, char* e
     if (po_prompt(m, st, emb, tp)) { free(emb); po_state_free(st); FAIL("generate: prompt flow state: failed"); }
     free(emb);
     float* frames = fzeros((int64_t)max_steps * L);
+    float* logits = fzeros(max_steps);
     float* cur = (float*)xmalloc(sizeof(float) * (size_t)L);
     for (int64_t i = 0; i < L; i++) cur[i] = NAN;                             /* newBOSSequenceTensor :246-253 */
     int n_frames = 0, countdown = 0, have_countdown = 0;
     for (int step = 0; step < max_steps; step++) {                            /* :155-201 */
         int is_eos = 0;
         float* fo = frames + (int64_t)step * L;
-        int rc = po_step(m, st, cur, lsd, rq->eos_threshold, rq->noise ? rq->noise + (int64_t)step * L : NULL, fo, &is_eos, NULL, NULL);
-        if (rc) { free(frames); free(cur); po_state_free(st); FAIL("generate step %d: failed", step); }
+        int rc = po_step(m, st, cur, lsd, rq->eos_threshold, rq->noise ? rq->noise + (int64_t)step * L : NULL, fo, &is_eos, &logits[step], NULL);
+        if (rc) { free(frames); free(logits); free(cur); po_state_free(st); FAIL("generate step %d: failed", step); }
         n_frames++;
         if (is_eos && !have_countdown) { have_countdown = 1; countdown = rq->frames_after_eos; res->eos_step = step; }
         if (have_countdown) { if (countdown == 0) break; countdown--; }
@@ -1313,14 +1328,14 @@ int po_generate(const po_model* m, const po_request* rq, po_result* res, char* e
     po_latent_to_mimi(m, frames, T, ml);
     int64_t n_samples = po_mimi_out_len(m, T);
     res->pcm = fzeros(n_samples);
-    if (po_mimi_decode(m, ml, T, res->pcm)) { free(ml); free(frames); free(res->pcm); res->pcm = NULL; FAIL("generate: mimi_decode: failed"); }
+    if (po_mimi_decode(m, ml, T, res->pcm)) { free(ml); free(frames); free(logits); free(res->pcm); res->pcm = NULL; FAIL("generate: mimi_decode: failed"); }
     free(ml);
     res->n_samples = n_samples;
-    res->latents = frames; res->n_frames = n_frames;
+    res->latents = frames; res->n_frames = n_frames; res->eos_logits = logits;
     return 0;
 }
 
-void po_free_result(po_result* r) { if (!r) return; free(r->pcm); free(r->latents); r->pcm = NULL; r->latents = NULL; }
+void po_free_result(po_result* r) { if (!r) return; free(r->pcm); free(r->latents); free(r->eos_logits); r->pcm = NULL; r->latents = NULL; r->eos_logits = NULL; }
 
 /* ---- PCM egress: internal/audio/wav_stream.go ---- */
 /* WritePCM16Samples (:43-54): clamped := math.Max(-1, math.Min(1, float64(s))); v := int16(clamped * 32767).

@@ -118,6 +118,11 @@ int po_flow_direction(const po_model*, const float* c, float s, float t, const f
 int po_latent_to_mimi(const po_model*, const float* latent, int64_t t, float* out /*[512,T]*/);      /* model.go:141-319 */
 int po_mimi_decode(const po_model*, const float* x /*[512,T]*/, int64_t t, float* pcm /*[1920*T]*/);  /* mimi.go:719-789 */
 int64_t po_mimi_out_len(const po_model*, int64_t t);
+/* staged: the decoder transformer's output (upsample + every mimiTransformerLayer, mimi.go:733-748) as [16 T, 512] rows */
+int po_mimi_transformer(const po_model*, const float* x /*[512,T]*/, int64_t t, float* out /*[16*T, 512]*/);
+/* test-only: overrides the attention window of every Mimi layer (DefaultMimiConfig: 250, mimi.go:32) so that a parity test can
+ * show that it would notice a wrong window */
+void po_debug_set_mimi_context(po_model*, int64_t context);
 
 typedef struct po_request {
     const int64_t* tokens; int64_t n_tokens;
@@ -136,6 +141,7 @@ typedef struct po_result {
     float*  pcm;      int64_t n_samples;
     float*  latents;  int32_t n_frames;
     int32_t eos_step; /* -1 if none */
+    float*  eos_logits; /* [n_frames]: out_eos of every step taken (flow_lm.go:262-281), for threshold-margin checks */
 } po_result;
 
 /* runtime_native_safetensors.go:52-238 */

@@ -1,10 +1,24 @@
 """GPU parity at the reference's full shapes (`tts_b6369a24`: 6 x 1024-wide layers, ffn 4096, flow net 512 x 6,
 Mimi 512 + SEANet 512/256/128/64) -- the shapes bench.py measures, on a synthetic checkpoint with the reference's tensor names.
 
-The oracle finishes a few frames of the full model in seconds, so the head of an utterance is compared against it directly;
-the full batch is covered through properties that do not depend on size: the same request in two slots of a 64-utterance
-batch gives the same bits, whatever else shares the batch.
+BASELINE.json configs[1] (batch 1, f32, 63 frames) and configs[2] (batch 64, bf16 weights + KV, 125 frames, graph replay) are
+compared with the oracle over their FULL length, frame by frame (the oracle needs a few seconds for a 63-frame utterance); the
+error curves go to gpurun_out/parity_curve_*.json.
+
+What "full length" can mean on random-init weights.  The AR loop feeds each frame back in, and on a random-init checkpoint that
+map is expanding: ANY rounding difference grows ~1.15x per step.  The reference itself shows it -- its AVX2 build and its
+scalar build (`just bench-stageprof-asm|noavx`; dot_amd64.s vs the generic loop: the oracle restates both summation orders)
+start 2.6e-6 apart and are 1.5e-2 apart after 63 frames (measured here, test below).  So the frames of a long FREE-RUNNING
+utterance are not a function any two correct implementations agree on, and the per-frame check is made TEACHER-FORCED instead:
+at every step the GPU path is handed the oracle's previous frame (through the staged entry points = the native.Model methods),
+so each of the 63 / 125 steps -- growing cache, bf16 keys and values, every kernel of the step -- is compared at the same
+operating point, and the tolerance stays a single-step tolerance.  The free-running run is then held to the envelope the
+reference's own two summation orders span, to bit-identity between graph replay and plain launches, and to exact EOS step /
+frame count for a threshold the oracle's logits clear with a margin.
+The 64-utterance batch is also covered through properties that do not depend on size: the same request in two slots gives
+the same bits, whatever else shares the batch.
 """
+import json
 import os
 import sys
 
@@ -13,19 +27,86 @@ import pytest
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle as O
+from _parity import parity as _parity, record
 
 pytestmark = pytest.mark.gpu
 
+# Tolerances are set from the errors observed on MI355X (profiles/r2_parity_observed.json), at most 10x above them.
+# teacher-forced steps: max |frame error| / max|frames| and |logit error| at EVERY step of the run
+TF_F32_FRAME, TF_F32_LOGIT = 2e-4, 2e-4          # the reference's flow-step budget (python_parity_test.go:86)
+TF_BF16_FRAME, TF_BF16_LOGIT = 3e-2, 3e-2        # bf16 keys / values (8-bit mantissa), not a reference mode
+# free-running head of an utterance (3 / 6 frames)
+HEAD_F32_LAT, HEAD_F32_PCM = (2e-3, 5e-2), (5e-3, None)
+HEAD_BF16_LAT, HEAD_BF16_PCM = (3e-2, None), (3e-2, None)
+# free-running, whole length: GPU-vs-oracle error at step t over the running maximum of the reference's own AVX2-vs-scalar
+# difference up to t (both amplified by the model's dynamics at the same rate; the GPU's bf16 hi/lo operand split starts ~13x
+# above a pure summation-order change)
+ENVELOPE_FACTOR = 100.0
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def parity(name, got, want, abs_tol, rel_tol=None):
-    got, want = np.asarray(got, np.float64), np.asarray(want, np.float64)
-    assert got.shape == want.shape and np.isfinite(got).all(), name
-    err = np.abs(got - want)
-    scale = max(1.0, np.abs(want).max())
-    assert err.max() <= abs_tol * scale, f"{name}: max abs {err.max():.3e} (scale {scale:.2f})"
-    if rel_tol is not None:
-        big = np.abs(want) >= 1e-3 * np.abs(want).max()
-        assert (err[big] / np.abs(want[big])).max() <= rel_tol, name
+    return _parity(name, got, want, (abs_tol, rel_tol))
+
+
+def error_curve(name, got, ref, spf=1920):
+    """Per-frame max |error| of latents and samples (absolute; the scales ride along), written next to the other GPU evidence."""
+    n = ref["n_frames"]
+    lat = np.abs(np.asarray(got.latents, np.float64) - ref["latents"]).max(axis=1)
+    pcm_ref = np.asarray(ref["pcm"], np.float64)
+    pcm_got = np.asarray(got.pcm, np.float64)
+    if got.pcm.dtype == np.int16:
+        pcm_got = pcm_got / 32767.0
+    pcm = np.abs(pcm_got - pcm_ref).reshape(n, spf).max(axis=1)
+    out = {"name": name, "frames": n, "latent_scale": float(np.abs(ref["latents"]).max()), "pcm_scale": float(np.abs(pcm_ref).max()),
+           "latent_max_abs_per_frame": [float(x) for x in lat], "pcm_max_abs_per_frame": [float(x) for x in pcm]}
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", f"parity_curve_{name}.json"), "w") as f:
+            json.dump(out, f)
+    except OSError:
+        pass
+    print(f"[curve] {name}: latent err first/mid/last = {lat[0]:.2e} / {lat[n // 2]:.2e} / {lat[-1]:.2e} (scale {out['latent_scale']:.2f}); "
+          f"pcm err = {pcm[0]:.2e} / {pcm[n // 2]:.2e} / {pcm[-1]:.2e} (scale {out['pcm_scale']:.3f})")
+    return lat, pcm
+
+
+def pick_threshold(logits, lo=1, hi=24):
+    """A finite EOS threshold from the oracle's own logits: the step in [lo, hi) whose logit exceeds every earlier one by the
+    widest margin (EOS fires at the FIRST logit above the threshold, so the step must be a running maximum); the threshold sits
+    in the middle of that gap.  Early steps only: the free-running trajectories still agree there.  Returns (threshold, step, margin)."""
+    best = None
+    for s in range(lo, min(hi, len(logits) - 4)):
+        m = float(logits[s] - logits[:s].max())
+        if best is None or m > best[2]:
+            best = ((float(logits[s]) + float(logits[:s].max())) / 2, s, m)
+    return best
+
+
+def teacher_forced(pkg, gm, om, toks_by_slot, voice, refs, steps, n_slots, cap):
+    """Steps the GPU batch through `steps` frames; slots listed in `refs` get the oracle's previous frame as input at every step
+    (BOS at step 0), the others feed themselves.  Returns per reference slot the per-step max |frame error| and |logit error|."""
+    b = gm.new_batch(n_slots, cap)
+    vs = pkg.VoiceModelState(voice)
+    for sl in range(n_slots):
+        b.set_voice_state(sl, vs)
+    b.prompt([gm.text_embeddings(toks_by_slot[sl]) for sl in range(n_slots)])
+    frames = np.full((n_slots, 32), np.nan, np.float32)
+    err = {sl: ([], []) for sl in refs}
+    for t in range(steps):
+        for sl, ref in refs.items():
+            if t > 0:
+                frames[sl] = ref["latents"][t - 1]
+        out, logit, _ = b.step(frames)
+        for sl, ref in refs.items():
+            err[sl][0].append(float(np.abs(out[sl].astype(np.float64) - ref["latents"][t]).max()))
+            err[sl][1].append(float(abs(float(logit[sl]) - float(ref["eos_logits"][t]))))
+        frames = out.copy()
+    assert list(b.offsets()) == [125 + len(toks_by_slot[sl]) + steps for sl in range(n_slots)]
+    b.close()
+    return err
+
 
 
 @pytest.fixture(scope="module")
@@ -48,8 +129,8 @@ def test_full_size_head_of_an_utterance_against_the_oracle(pkg, full):
     got = pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=3, want_latents=True,
                                                                     voice_model_state=pkg.VoiceModelState(voice)))
     assert got.n_frames == ref["n_frames"] == 3
-    parity("latents", got.latents, ref["latents"], 2e-3, 5e-2)
-    parity("pcm", got.pcm, ref["pcm"], 5e-3)
+    parity("fullsize head latents (3 frames, f32)", got.latents, ref["latents"], *HEAD_F32_LAT)
+    parity("fullsize head pcm (3 frames, f32)", got.pcm, ref["pcm"], *HEAD_F32_PCM)
     gm.close()
     om.close()
 
@@ -82,8 +163,108 @@ def test_full_size_batch_of_64_is_slot_independent_and_tracks_the_oracle(pkg, fu
     assert np.abs(head).max() <= 1
     om = O.OracleModel.from_file(paths["BF16"])
     ref = om.generate(toks[0], max_steps=6, eos_threshold=1e30, frames_after_eos=3, voice_state=voice)
-    parity("latents[0] (bf16 cache)", out[0].latents, ref["latents"], 3e-2)
-    parity("pcm[0] (bf16 cache)", out[0].pcm, ref["pcm"], 3e-2)
+    parity("fullsize head latents[0] (6 frames, bf16 weights + cache)", out[0].latents, ref["latents"], *HEAD_BF16_LAT)
+    parity("fullsize head pcm[0] (6 frames, bf16 weights + cache)", out[0].pcm, ref["pcm"], *HEAD_BF16_PCM)
+    dv.close()
+    gm.close()
+    om.close()
+
+
+def test_config1_full_length_63_frames_f32(pkg, full):
+    """BASELINE configs[1]: batch 1, f32 weights and cache, 25 tokens on the 125-frame voice state, 63 frames (5.04 s)."""
+    cfg, paths, voice = full
+    om = O.OracleModel.from_file(paths["F32"])
+    gm = pkg.Model.open(paths["F32"], device=0, weights=pkg.WEIGHTS_F32, kv=pkg.KV_F32, max_batch=4)
+    toks = pkg.synth.make_prompts(1, 25, 4000, seed=42)[0]
+    O.set_use_avx2(True)
+    ref = om.generate(toks, max_steps=63, eos_threshold=1e30, frames_after_eos=3, voice_state=voice)
+    O.set_use_avx2(False)   # the reference's scalar build: same arithmetic, another summation order
+    ref_scalar = om.generate(toks, max_steps=63, eos_threshold=1e30, frames_after_eos=3, voice_state=voice)
+    O.set_use_avx2(True)
+    scale = float(np.abs(ref["latents"]).max())
+    # 1. teacher-forced: all 63 steps at the oracle's operating point
+    err = teacher_forced(pkg, gm, om, [toks], voice, {0: ref}, 63, 1, 125 + 25 + 63)[0]
+    fe, le = max(err[0]), max(err[1])
+    print(f"[tf] config1 f32: max frame err {fe:.2e} (scale {scale:.2f}; first / last step {err[0][0]:.2e} / {err[0][-1]:.2e}), max logit err {le:.2e}")
+    record("config1 teacher-forced frames (63 steps, f32)", fe, 0.0, scale, (TF_F32_FRAME, 0))
+    record("config1 teacher-forced eos logits (63 steps, f32)", le, 0.0, float(np.abs(ref["eos_logits"]).max()), (TF_F32_LOGIT, 0))
+    assert fe <= TF_F32_FRAME * max(1.0, scale) and le <= TF_F32_LOGIT * max(1.0, float(np.abs(ref["eos_logits"]).max())), (fe, le)
+    # 2. free-running: inside the envelope of the reference's own two summation orders; graph replay == plain launches
+    c = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=63, want_latents=True, voice_model_state=pkg.VoiceModelState(voice))
+    got = pkg.Runtime(gm).generate(toks, c)
+    assert got.n_frames == ref["n_frames"] == 63
+    lat, _ = error_curve("config1_f32_63", got, ref)
+    own = np.abs(ref["latents"].astype(np.float64) - ref_scalar["latents"]).max(axis=1)
+    ratio = float((lat / np.maximum.accumulate(own)).max())
+    print(f"[free] reference AVX2 vs scalar order: {own[0]:.2e} -> {own[-1]:.2e}; GPU vs oracle: {lat[0]:.2e} -> {lat[-1]:.2e}; max ratio {ratio:.1f}")
+    record("config1 free-running: GPU error / reference's own AVX2-vs-scalar envelope (63 frames)", ratio, 0.0, 1.0, (ENVELOPE_FACTOR, 0))
+    assert ratio <= ENVELOPE_FACTOR, ratio
+    gm.set_use_graph(True)
+    again = pkg.Runtime(gm).generate(toks, c)
+    assert np.array_equal(again.latents, got.latents) and np.array_equal(again.pcm, got.pcm)
+    # 3. EOS step and frame count under a finite threshold the oracle's logits clear with a margin far above the logit error
+    thr, s_eos, margin = pick_threshold(ref["eos_logits"])
+    record("config1 eos margin (oracle logits)", margin, 0.0, float(np.abs(ref["eos_logits"]).max()), (0, 0))
+    assert margin > 20 * le, (margin, le)
+    ref_eos = om.generate(toks, max_steps=63, eos_threshold=thr, frames_after_eos=3, voice_state=voice)
+    assert ref_eos["eos_step"] == s_eos and ref_eos["n_frames"] == s_eos + 4
+    for graph in (False, True):
+        gm.set_use_graph(graph)
+        ge = pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=thr, max_steps=63, frames_after_eos=3, want_latents=True,
+                                                                       voice_model_state=pkg.VoiceModelState(voice)))
+        assert (ge.eos_step, ge.n_frames) == (ref_eos["eos_step"], ref_eos["n_frames"]), (graph, ge.eos_step, ge.n_frames, margin)
+        assert ge.pcm.shape == ref_eos["pcm"].shape
+    gm.close()
+    om.close()
+
+
+def test_config2_full_length_125_frames_bf16(pkg, full):
+    """BASELINE configs[2]: 64 utterances, bf16 weights AND bf16 KV cache, 125 frames; graph replay (five steps per replay)
+    for the free-running part.  Slots 0 and 37 against the oracle run on the same BF16 file (the oracle keeps an f32 cache: the
+    bf16 cache's 8-bit mantissa on keys and values is the error measured here)."""
+    cfg, paths, voice = full
+    om = O.OracleModel.from_file(paths["BF16"])
+    gm = pkg.Model.open(paths["BF16"], device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=64, use_graph=True)
+    toks = pkg.synth.make_prompts(64, 25, 4000, seed=42)
+    refs = {sl: om.generate(toks[sl], max_steps=125, eos_threshold=1e30, frames_after_eos=3, voice_state=voice) for sl in (0, 37)}
+    # 1. teacher-forced: all 125 steps of slots 0 and 37 at the oracle's operating point, inside the full batch of 64
+    err = teacher_forced(pkg, gm, om, list(toks), voice, refs, 125, 64, 125 + 25 + 125)
+    le_max = 0.0
+    for sl, ref in refs.items():
+        scale = float(np.abs(ref["latents"]).max())
+        fe, le = max(err[sl][0]), max(err[sl][1])
+        le_max = max(le_max, le)
+        print(f"[tf] config2 bf16 slot {sl}: max frame err {fe:.2e} (scale {scale:.2f}; first / last step {err[sl][0][0]:.2e} / {err[sl][0][-1]:.2e}), max logit err {le:.2e}")
+        record(f"config2 teacher-forced frames[{sl}] (125 steps, bf16 weights + KV, batch 64)", fe, 0.0, scale, (TF_BF16_FRAME, 0))
+        record(f"config2 teacher-forced eos logits[{sl}] (125 steps, bf16 weights + KV, batch 64)", le, 0.0, float(np.abs(ref["eos_logits"]).max()), (TF_BF16_LOGIT, 0))
+        assert fe <= TF_BF16_FRAME * max(1.0, scale) and le <= TF_BF16_LOGIT * max(1.0, float(np.abs(ref["eos_logits"]).max())), (sl, fe, le)
+    # 2. free-running at full length, graph replay: curve on record; bit-identical to plain launches
+    dv = gm.upload_voice(pkg.VoiceModelState(voice))
+    c = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=125, want_latents=True, device_voice=dv)
+    out = gm.generate_batch(list(toks), [c] * 64)
+    assert all(o.n_frames == 125 for o in out)
+    for sl, ref in refs.items():
+        error_curve(f"config2_bf16_125_slot{sl}", out[sl], ref)
+    gm.set_use_graph(False)
+    plain = gm.generate_batch(list(toks), [c] * 64)
+    for sl in (0, 37, 63):
+        assert np.array_equal(plain[sl].latents, out[sl].latents) and np.array_equal(plain[sl].pcm, out[sl].pcm), sl
+    gm.set_use_graph(True)
+    # 3. finite EOS threshold per slot (each utterance stops on its own; the batch runs on until the last one has)
+    thr0, s0, m0 = pick_threshold(refs[0]["eos_logits"])
+    thr1, s1, m1 = pick_threshold(refs[37]["eos_logits"])
+    record("config2 eos margin slot 0 (oracle logits)", m0, 0.0, float(np.abs(refs[0]["eos_logits"]).max()), (0, 0))
+    record("config2 eos margin slot 37 (oracle logits)", m1, 0.0, float(np.abs(refs[37]["eos_logits"]).max()), (0, 0))
+    assert min(m0, m1) > 10 * le_max, (m0, m1, le_max)
+    cfgs = [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=125, device_voice=dv) for _ in range(64)]
+    cfgs[0] = pkg.RuntimeGenerateConfig(eos_threshold=thr0, max_steps=125, frames_after_eos=3, device_voice=dv)
+    cfgs[37] = pkg.RuntimeGenerateConfig(eos_threshold=thr1, max_steps=125, frames_after_eos=2, device_voice=dv)
+    ge = gm.generate_batch(list(toks), cfgs)
+    assert (ge[0].eos_step, ge[0].n_frames) == (s0, s0 + 4), (ge[0].eos_step, ge[0].n_frames, s0, m0)
+    assert (ge[37].eos_step, ge[37].n_frames) == (s1, s1 + 3), (ge[37].eos_step, ge[37].n_frames, s1, m1)
+    assert ge[1].n_frames == 125 and ge[1].eos_step == -1
+    # the frames an utterance produced before it stopped are the frames of the unbounded run
+    assert np.array_equal(ge[0].pcm, out[0].pcm[: ge[0].pcm.shape[0]])
     dv.close()
     gm.close()
     om.close()

@@ -63,3 +63,36 @@ def test_two_rank_startup_protocol(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), path, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / f"ok{r}") for r in range(world))
+
+
+def _run_bench(*args):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (fresh children; the parent never touches a
+    GPU): the CPU rehearsal runs the start-up protocol through exactly that path and reports n_gpus == rccl_ranks == 2."""
+    import json
+    r = _run_bench("--gpus", "2", "--startup-only")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == line["rccl_ranks"] == 2 and line["ok"] and line["arena_matches_local_fill"]
+
+
+def test_bench_without_gpus_fails_fast_from_every_rank():
+    """On a box without GPUs the two children say so and the parent exits non-zero: no silent one-GPU run labelled --gpus 2."""
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0
+    assert "rank 0 of 2" in r.stderr and "rank 1 of 2" in r.stderr and "no HIP device" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_a_rank_count_that_disagrees_with_the_launcher():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
