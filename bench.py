@@ -197,12 +197,20 @@ def roofline_pass(pkg, model, wl, prompts, voice, traffic=None):
     durations; the same with the activation rows in and the outputs counted is reported beside it."""
     cfgs = gen_cfgs(pkg, wl, len(prompts), voice)
     toks = [np.ascontiguousarray(p, np.int64) for p in prompts]
-    model.profile_enable(True)
+    model.profile_enable(2)   # phases only: the call runs as configured (graph replay), HIP events at the phase boundaries
+    try:
+        model.generate_batch(toks, cfgs)
+        phases = model.profile_read()
+    finally:
+        model.profile_enable(False)
+    model.profile_enable(True)   # every launch of the dominant kernel timed (plain launches)
     try:
         model.generate_batch(toks, cfgs)
         prof = model.profile_read()
     finally:
         model.profile_enable(False)
+    for k in ("prefill_ms", "ar_loop_ms", "mimi_ms"):
+        prof[k] = phases[k]
     sec = prof["total_ms"] * 1e-3
     n = max(1, prof["launches"])
     achieved = prof["weight_bytes"] / sec / 1e9 if sec > 0 else 0.0
@@ -340,28 +348,53 @@ def cpu_baseline(pkg, path, cfg, frames=63, runs=5):
     toks = pkg.synth.make_prompts(1, 25, 4000, seed=42)[0]
     model, logical, usable, physical = host_cpu()
     O.set_use_avx2(True)
-    legs = {}
-    budget_end = time.perf_counter() + 45.0
-    for name, workers in (("reference_default_2_workers", 2), ("all_physical_cores", physical)):
+
+    def one(workers, n_frames):
         O.set_workers(workers, workers)   # conv-workers / runtime-workers (config.go:76-83, service.go:318-328)
-        times = []
-        for i in range(1 + runs):
-            t0 = time.perf_counter()
-            r = om.generate(toks, max_steps=frames, eos_threshold=1e30, frames_after_eos=3, voice_state=mods)
-            dt = time.perf_counter() - t0
-            assert r["n_frames"] == frames
-            if i > 0:
-                times.append(dt)
-            if time.perf_counter() > budget_end and len(times) >= 2:
-                break
+        t0 = time.perf_counter()
+        r = om.generate(toks, max_steps=n_frames, eos_threshold=1e30, frames_after_eos=3, voice_state=mods)
+        assert r["n_frames"] == n_frames
+        return time.perf_counter() - t0
+
+    def leg(workers):   # 1 warm-up + >= 5 timed utterances, p50
+        one(workers, frames)
+        times = [one(workers, frames) for _ in range(runs)]
         p50 = statistics.median(times)
-        legs[name] = {"workers": workers, "p50_latency_ms": round(1e3 * p50, 1), "xrt": round(frames * FRAME_SEC / p50, 3), "timed_runs": len(times)}
+        return {"workers": workers, "p50_latency_ms": round(1e3 * p50, 1), "xrt": round(frames * FRAME_SEC / p50, 3), "timed_runs": runs, "frames": frames}
+
+    legs = {"reference_default_2_workers": leg(2)}
+    # the reference's fork-join split (one goroutine per worker and per operator) stops paying long before a 128-core host is
+    # full: a short utterance per worker count finds where, the full protocol then runs at the best count; the all-cores
+    # figure BASELINE.md asks for is reported from its short sample when it is the slow end of that curve
+    short = 8
+    sweep = {}
+    for w in sorted({4, 8, 16, 32, 64, physical}):
+        if w > physical or w <= 2:
+            continue
+        dt = one(w, short)
+        sweep[w] = round(short * FRAME_SEC / dt, 3)
+        if dt > 6.0:
+            break
+    best_w = max(sweep, key=sweep.get) if sweep else 2
+    if sweep and sweep[best_w] > legs["reference_default_2_workers"]["xrt"] * short / frames:   # worth the full protocol
+        legs["best_worker_count"] = leg(best_w)
+    if physical in sweep:
+        if physical == best_w and "best_worker_count" in legs:
+            legs["all_physical_cores"] = legs["best_worker_count"]
+        else:
+            legs["all_physical_cores"] = {"workers": physical, "xrt": sweep[physical], "timed_runs": 1, "frames": short,
+                                          "note": "short sample: slower than fewer workers (fork-join overhead per operator)"}
+    else:
+        legs["all_physical_cores"] = {"workers": physical, "xrt": None, "note": f"not run: already {min(sweep.values()) if sweep else 0} x real-time "
+                                                                              f"at {max(sweep) if sweep else 0} workers and falling"}
     om.close()
-    best = max(legs.values(), key=lambda v: v["xrt"])
+    full = [v for v in legs.values() if v.get("timed_runs") == runs]
+    best = max(full, key=lambda v: v["xrt"])
     return {"value": best["xrt"], "unit": "x real-time", "cores": best["workers"], "kind": "port",
             "sample": f"1 warm-up + {runs} timed utterances per leg, one after the other (batch 1: the reference has no batching), 25 tokens on a "
-                      f"125-frame voice state, {frames} frames = {frames*FRAME_SEC:.2f} s of audio each, f32 math on the same checkpoint shapes; p50",
-            "legs": legs, "cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "physical_cores": physical}
+                      f"125-frame voice state, {frames} frames = {frames*FRAME_SEC:.2f} s of audio each, f32 math on the same checkpoint shapes; p50; "
+                      f"worker-count sweep on {short}-frame utterances",
+            "legs": legs, "worker_sweep_xrt": sweep, "cpu_model": model, "logical_cpus": logical, "usable_cpus": usable, "physical_cores": physical}
 
 
 def main():

@@ -333,7 +333,8 @@ int ptts_profile_enable(ptts_model* h, int32_t on) {
     return guard([&] {
         if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
         std::lock_guard<std::mutex> lock(h->m->mu);
-        h->m->prof.on = on != 0;
+        h->m->prof.on = on == 1;          // 1: per-launch events (plain launches) + phases; 2: phases only
+        h->m->prof.phases_on = on != 0;
         h->m->prof.used = 0; h->m->prof.bytes = 0; h->m->prof.wbytes = 0; h->m->prof.launches = 0; h->m->prof.phases = false;
     });
 }

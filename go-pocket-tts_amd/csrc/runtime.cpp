@@ -1123,7 +1123,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     }
     mark("setup");
     auto phase = [&](int i, hipStream_t st) {   // measurement pass only (ptts_profile_enable): device time of the call's phases
-        if (!m.prof.on) return;
+        if (!m.prof.phases_on) return;
         if (!m.prof.phase[i]) PTTS_HIP(hipEventCreate(&m.prof.phase[i]));
         PTTS_HIP(hipEventRecord(m.prof.phase[i], st));
     };
@@ -1387,12 +1387,12 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             }
         }
         pcm_rows = d_rows; rows_used = &direct_done;
-        if (m.prof.on) { PTTS_HIP(hipStreamWaitEvent(m.stream2, m.prof.phase[2], 0)); phase(3, m.stream2); }
+        if (m.prof.phases_on) { PTTS_HIP(hipStreamWaitEvent(m.stream2, m.prof.phase[2], 0)); phase(3, m.stream2); }
         decode_upto(std::min(steps_run, Tmax));   // frames past every utterance's end are never decoded
         pcm_rows = nullptr; rows_used = nullptr;
         emit_upto(std::min(steps_run, Tmax));
         phase(4, m.stream2);
-        m.prof.phases = m.prof.on && f_done > 0;
+        m.prof.phases = m.prof.phases_on && f_done > 0;
         PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int32_t* p : stream_nf) (void)hipHostFree(p);
         stream_nf.clear();

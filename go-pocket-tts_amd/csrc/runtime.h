@@ -40,6 +40,7 @@ struct Prof {   // bench.py measurement hook (ptts_profile_*)
     double bytes = 0, wbytes = 0;
     int64_t launches = 0;
     hipEvent_t phase[5] = {};   // setup | prefill | AR loop on the model's stream; Mimi start | end on the decoder's stream
+    bool phases_on = false;     // record them (with or without the per-launch events of `on`)
     bool phases = false;
 };
 

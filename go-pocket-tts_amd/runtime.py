@@ -361,8 +361,8 @@ class Model:
         _check(lib().ptts_voice_create(self.h, ptrs, _ip(steps), _ip(offs), C.byref(h)))
         return DeviceVoice(h.value, int(offs[0]))
 
-    def profile_enable(self, on: bool):
-        _check(lib().ptts_profile_enable(self.h, 1 if on else 0))
+    def profile_enable(self, on):   # False / 0: off; True / 1: per-launch events + phases; 2: phases only
+        _check(lib().ptts_profile_enable(self.h, int(on)))
 
     def profile_read(self) -> dict:
         p = _Profile()

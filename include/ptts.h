@@ -233,7 +233,7 @@ typedef struct ptts_profile {
     double  weight_bytes;        /* the weights-only part of algorithmic_bytes (each step linear's matrix once per launch) */
     double  prefill_ms, ar_loop_ms, mimi_ms;   /* device time of the phases of the last ptts_generate call (HIP events on its streams) */
 } ptts_profile;
-int ptts_profile_enable(ptts_model* m, int32_t on);
+int ptts_profile_enable(ptts_model* m, int32_t on);   /* 0: off; 1: per-launch events (plain launches) + phase times; 2: phase times only (the call runs as configured) */
 int ptts_profile_read(ptts_model* m, ptts_profile* out);   /* returns and resets the counters */
 
 /* ---- staged entry points = the native.Model methods GenerateAudio calls (model.go:76-138,141,410).

@@ -33,15 +33,15 @@ pytestmark = pytest.mark.gpu
 
 # Tolerances are set from the errors observed on MI355X (profiles/r2_parity_observed.json), at most 10x above them.
 # teacher-forced steps: max |frame error| / max|frames| and |logit error| at EVERY step of the run
-TF_F32_FRAME, TF_F32_LOGIT = 2e-4, 2e-4          # the reference's flow-step budget (python_parity_test.go:86)
-TF_BF16_FRAME, TF_BF16_LOGIT = 3e-2, 3e-2        # bf16 keys / values (8-bit mantissa), not a reference mode
+TF_F32_FRAME, TF_F32_LOGIT = 1.6e-4, 1.3e-4      # observed 1.6e-5 / 1.3e-5 (the reference's flow-step budget is 2e-4, python_parity_test.go:86)
+TF_BF16_FRAME, TF_BF16_LOGIT = 2.7e-3, 1.8e-3    # observed 2.7e-4 / 1.8e-4; bf16 keys / values (8-bit mantissa), not a reference mode
 # free-running head of an utterance (3 / 6 frames)
-HEAD_F32_LAT, HEAD_F32_PCM = (2e-3, 5e-2), (5e-3, None)
-HEAD_BF16_LAT, HEAD_BF16_PCM = (3e-2, None), (3e-2, None)
+HEAD_F32_LAT, HEAD_F32_PCM = (2.5e-4, 6e-3), (2.4e-4, None)     # observed 2.5e-5 / 6.3e-4, 2.4e-5
+HEAD_BF16_LAT, HEAD_BF16_PCM = (1.4e-2, None), (1e-2, None)     # observed 1.4e-3, 1.1e-3
 # free-running, whole length: GPU-vs-oracle error at step t over the running maximum of the reference's own AVX2-vs-scalar
 # difference up to t (both amplified by the model's dynamics at the same rate; the GPU's bf16 hi/lo operand split starts ~13x
 # above a pure summation-order change)
-ENVELOPE_FACTOR = 100.0
+ENVELOPE_FACTOR = 100.0   # observed 27
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

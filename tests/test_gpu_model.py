@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 FLOW_TOL = (2e-4, 5e-3)
 # multi-step generation (accumulated rounding over autoregressive steps); set from the errors observed on MI355X
 # (profiles/r2_parity_observed.json), at most 10x above them
-MULTI_LAT_TOL = (2e-3, 5e-2)
-MULTI_PCM_TOL = (5e-3, 2e-1)
+MULTI_LAT_TOL = (2.5e-4, 5e-2)      # observed 3.0e-5 / 8.3e-3
+MULTI_PCM_TOL = (3e-4, 1e-1)        # observed 3.2e-5 / 1.4e-2
 # bf16 KV cache (8-bit mantissa on keys and values; not a reference mode): abs of max|want| and rel
-BF16KV_LAT_TOL = (3e-2, None)
-BF16KV_PCM_TOL = (2e-2, None)
+BF16KV_LAT_TOL = (3e-2, None)       # observed 3.2e-3
+BF16KV_PCM_TOL = (1.5e-2, None)     # observed 1.6e-3
 CONV_TOL = (2e-4, 1e-3)
 DECONV_TOL = (2e-4, 5e-2)
 
@@ -686,8 +686,8 @@ def test_long_utterance_beyond_the_one_burst_attention(pkg, tiny):
     got = gm.generate_batch([toks], [pkg.RuntimeGenerateConfig(max_steps=270, eos_threshold=1e30, want_latents=True)])[0]
     ref = om.generate(toks, max_steps=270, eos_threshold=1e30, frames_after_eos=3)
     assert got.n_frames == ref["n_frames"] == 270
-    parity("latents 270 steps", got.latents, ref["latents"], (5e-3, None))
-    parity("pcm 270 steps", got.pcm, ref["pcm"], (1e-2, None))
+    parity("latents 270 steps", got.latents, ref["latents"], (2e-3, None))   # observed 2.0e-4 (tiny model: its AR map is mildly expanding too)
+    parity("pcm 270 steps", got.pcm, ref["pcm"], (2.9e-3, None))   # observed 2.9e-4
     # graph replay of the same run: one captured step per attention round count (17 cache-length buckets are crossed here,
     # then the fallback kernel) -- the same kernels on the same data, so the result is identical
     gm.set_use_graph(True)
