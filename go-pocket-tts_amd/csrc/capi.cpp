@@ -692,6 +692,36 @@ int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, in
     });
 }
 
+// debug: one whole AR step of a prompted batch with every stampable launch of the step linear stamped in place (cold caches, the
+// real operands).  out: [cap_blocks][8] ticks; desc: [cap_desc][8] = M, N, K, prologue, NJ, CG, blocks, splitk per launch
+int ptts_debug_step_stamps(ptts_batch* hb, int32_t lsd_steps, uint64_t* out, int64_t cap_blocks, int32_t* desc, int32_t cap_desc, int32_t* n_desc) {
+    return guard([&] {
+        if (!hb || !hb->b || !out || !desc || !n_desc) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        Model& m = *hb->m;
+        Batch& b = *hb->b;
+        std::lock_guard<std::mutex> lock(m.mu);
+        m.use_device();
+        for (int i = 0; i < b.B; i++)
+            if (b.kv_len_host[i] + 1 > b.cap) throw Error(PTTS_EINVAL, "ptts-hip: KV capacity exhausted");
+        m.tcomb_for(lsd_steps);
+        Tmp ds((size_t)cap_blocks * 64);
+        PTTS_HIP(hipMemsetAsync(ds.p, 0, (size_t)cap_blocks * 64, m.stream));
+        PTTS_HIP(hipMemsetAsync(b.cur.p, 0, (size_t)b.B * m.d.ldim * sizeof(float), m.stream));
+        SkinnyStampLog lg;
+        lg.base = ds.as<unsigned long long>(); lg.cap_blocks = (size_t)cap_blocks;
+        g_skinny_stamp_log = &lg;
+        try { step_core(b, lsd_steps); } catch (...) { g_skinny_stamp_log = nullptr; throw; }
+        g_skinny_stamp_log = nullptr;
+        for (int i = 0; i < b.B; i++) b.kv_len_host[i] += 1;
+        PTTS_HIP(hipMemcpyAsync(b.st.kv_len, b.kv_len_host.data(), (size_t)b.B * sizeof(int32_t), hipMemcpyHostToDevice, m.stream));
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+        down(out, ds.p, lg.used_blocks * 64);
+        const int n = (int)std::min<size_t>(lg.desc.size(), (size_t)cap_desc);
+        for (int i = 0; i < n; i++) std::memcpy(desc + 8 * i, &lg.desc[(size_t)i], 32);
+        *n_desc = n;
+    });
+}
+
 // debug: time one many-row GEMM variant (2 = k_gemm2, 3 = k_gemm3) and compare it with the other one on pseudo-random data
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us, float* maxdiff) {
     return guard([&] {

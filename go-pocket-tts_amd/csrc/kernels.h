@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <map>
 #include <string>
+#include <vector>
 
 namespace ptts {
 
@@ -87,6 +88,14 @@ bool skinny_supported(const GemmArgs& a, int splitk);
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
 void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream);
 extern thread_local unsigned long long* g_skinny_stamps;
+// in-situ stamps of a whole AR step (ptts_debug_step_stamps): while set, every stampable launch of the step linear writes its
+// blocks' 8 ticks at base + 8 * used and notes its shape
+struct SkinnyStampLog {
+    unsigned long long* base = nullptr; size_t cap_blocks = 0, used_blocks = 0;
+    struct Desc { int32_t M, N, K, pro, nj, cg, blocks, splitk; };
+    std::vector<Desc> desc;
+};
+extern thread_local SkinnyStampLog* g_skinny_stamp_log;
 extern thread_local hipEvent_t g_skinny_ev[2];   // when set, launch_skinny times the dispatch with them (hipExtLaunchKernel)
 
 struct LnArgs {

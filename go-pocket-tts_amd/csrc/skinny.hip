@@ -441,6 +441,7 @@ bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
 
 thread_local hipEvent_t g_skinny_ev[2] = {nullptr, nullptr};   // measurement pass (bench.py roofline): the kernel's own begin / end timestamps
 thread_local unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_stamps)
+thread_local SkinnyStampLog* g_skinny_stamp_log = nullptr;    // debug (ptts_debug_step_stamps)
 
 template <bool WBF16, int PRO, int NJ, int CG>
 static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
@@ -452,6 +453,16 @@ static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
                                       a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
             else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial,
                                     (unsigned long long*)nullptr);
+            return;
+        }
+    }
+    if (SkinnyStampLog* lg = g_skinny_stamp_log) {
+        const size_t blocks = (size_t)grid.x * grid.y * grid.z;
+        if (lg->used_blocks + blocks <= lg->cap_blocks) {
+            hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial,
+                               lg->base + 8 * lg->used_blocks);
+            lg->used_blocks += blocks;
+            lg->desc.push_back(SkinnyStampLog::Desc{a.M, a.N, a.K, PRO, NJ, CG, (int32_t)blocks, splitk});
             return;
         }
     }

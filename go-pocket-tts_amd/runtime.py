@@ -91,7 +91,7 @@ ABI_SYMBOLS = [
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
     "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_noise_rows", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
-    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm",
+    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
     "ptts_model_share", "ptts_model_set_use_graph", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",

@@ -289,6 +289,8 @@ int ptts_op_convtr1d_righttrim(const float* x /* [B,Cin,L] */, const float* w /*
 int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, int32_t iters, float* avg_us);
 int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, uint64_t* out /* [max_blocks][8] */,
                              int32_t max_blocks, int32_t* n_blocks);
+int ptts_debug_step_stamps(ptts_batch* b, int32_t lsd_steps, uint64_t* out /* [cap_blocks][8] */, int64_t cap_blocks, int32_t* desc /* [cap_desc][8] */,
+                           int32_t cap_desc, int32_t* n_desc);
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
 
