@@ -231,8 +231,62 @@ int ptts_text_prepare(const char* utf8, int64_t len, char* out, int64_t cap, int
     });
 }
 
+struct ptts_tokenizer { Tokenizer* t; };
+
+int ptts_tokenizer_open(const char* model_path, ptts_tokenizer** out) {
+    return guard([&] {
+        if (!out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::unique_ptr<ptts_tokenizer> h(new ptts_tokenizer());
+        h->t = tokenizer_from_path(model_path ? model_path : "");
+        *out = h.release();
+    });
+}
+
+int ptts_tokenizer_open_bytes(const void* data, size_t len, ptts_tokenizer** out) {
+    return guard([&] {
+        if (!out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::unique_ptr<ptts_tokenizer> h(new ptts_tokenizer());
+        h->t = tokenizer_from_bytes(data, len);
+        *out = h.release();
+    });
+}
+
+void ptts_tokenizer_free(ptts_tokenizer* t) {
+    if (!t) return;
+    tokenizer_free(t->t);
+    delete t;
+}
+
+int64_t ptts_tokenizer_vocab_size(const ptts_tokenizer* t) { return t && t->t ? (int64_t)tokenizer_vocab(*t->t) : 0; }
+
+int64_t ptts_tokenizer_encode(const ptts_tokenizer* t, const char* utf8, int64_t len, int64_t* ids, int64_t cap) {
+    int64_t n = -1;
+    guard([&] {
+        if (!t || !t->t) throw Error(PTTS_EINVAL, "tokenizer is nil");
+        if ((!utf8 && len > 0) || len < 0) throw Error(PTTS_EINVAL, "tokenizer: nil text");
+        const std::vector<int64_t> v = tokenizer_encode(*t->t, std::string(utf8 ? utf8 : "", (size_t)len));
+        for (int64_t i = 0; i < (int64_t)v.size() && i < cap && ids; i++) ids[i] = v[(size_t)i];
+        n = (int64_t)v.size();
+    });
+    return n;
+}
+
+int64_t ptts_tokenizer_encode_cb(void* user, const char* utf8, int64_t len, int64_t* ids, int64_t cap) {
+    return ptts_tokenizer_encode(reinterpret_cast<const ptts_tokenizer*>(user), utf8, len, ids, cap);
+}
+
+int ptts_text_nfkc(const char* utf8, int64_t len, char* out, int64_t cap, int64_t* out_len) {
+    return guard([&] {
+        if ((!utf8 && len > 0) || len < 0 || !out_len) throw Error(PTTS_EINVAL, "text: nil argument");
+        const std::string r = nfkc_utf8(std::string(utf8 ? utf8 : "", (size_t)len));
+        *out_len = (int64_t)r.size();
+        if (out && cap > 0) std::memcpy(out, r.data(), (size_t)std::min<int64_t>(cap, (int64_t)r.size()));
+    });
+}
+
 int ptts_text_chunks(const char* utf8, int64_t len, ptts_encode_fn encode, void* user, int32_t max_tokens, double frame_rate, ptts_chunks** out) {
     return guard([&] {
+        if (!encode && user) encode = ptts_tokenizer_encode_cb;   // default encoder: `user` is a ptts_tokenizer
         if ((!utf8 && len > 0) || len < 0 || !encode || !out) throw Error(PTTS_EINVAL, "text: nil argument");
         TextEncodeFn enc = [&](const std::string& t) {
             std::vector<int64_t> ids(64);

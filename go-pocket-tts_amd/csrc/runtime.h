@@ -197,6 +197,15 @@ std::string text_prepare(const std::string& input);
 std::vector<std::string> text_split_sentences(const std::string& text);
 std::vector<TextChunk> text_chunks(const std::string& input, const TextEncodeFn& encode, int max_tokens, double frame_rate);
 
+// SentencePiece unigram encoder (tokenizer.cpp; internal/tokenizer/sentencepiece.go, sentencepiece_bytes_wasm.go)
+struct Tokenizer;
+Tokenizer* tokenizer_from_bytes(const void* data, size_t len);
+Tokenizer* tokenizer_from_path(const std::string& path);
+std::vector<int64_t> tokenizer_encode(const Tokenizer& t, const std::string& text);
+size_t tokenizer_vocab(const Tokenizer& t);
+void tokenizer_free(Tokenizer* t);
+std::string nfkc_utf8(const std::string& s);
+
 // request dispatcher (dispatcher.cpp)
 struct Dispatcher;
 typedef int (*ExecFn)(void* user, int worker, const ptts_request* reqs, int32_t n, ptts_result* results, char* err, int32_t errlen);

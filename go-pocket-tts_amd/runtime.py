@@ -96,6 +96,8 @@ ABI_SYMBOLS = [
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
     "ptts_model_share", "ptts_model_set_use_graph", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
+    "ptts_tokenizer_open", "ptts_tokenizer_open_bytes", "ptts_tokenizer_free", "ptts_tokenizer_vocab_size", "ptts_tokenizer_encode",
+    "ptts_tokenizer_encode_cb", "ptts_text_nfkc",
 ]
 
 
@@ -807,6 +809,67 @@ class Dispatcher:
 
 
 # ---- text front end (internal/text/prepare.go) ---------------------------------------------------------
+class Tokenizer:
+    """tokenizer.Tokenizer (internal/tokenizer/tokenizer.go) backed by the library's SentencePiece unigram encoder
+    (NewSentencePieceTokenizer / NewSentencePieceTokenizerFromBytes, sentencepiece.go:19-33)."""
+
+    def __init__(self, model):
+        L = lib()
+        L.ptts_tokenizer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ptts_tokenizer_open_bytes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ptts_tokenizer_free.argtypes = [C.c_void_p]
+        L.ptts_tokenizer_vocab_size.argtypes = [C.c_void_p]
+        L.ptts_tokenizer_vocab_size.restype = C.c_int64
+        L.ptts_tokenizer_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, _IP, C.c_int64]
+        L.ptts_tokenizer_encode.restype = C.c_int64
+        h = C.c_void_p()
+        if isinstance(model, (bytes, bytearray)):
+            buf = bytes(model)
+            _check(L.ptts_tokenizer_open_bytes(buf, len(buf), C.byref(h)))
+        else:
+            _check(L.ptts_tokenizer_open(str(model).encode(), C.byref(h)))
+        self.h = h.value
+
+    @property
+    def vocab_size(self) -> int:
+        return int(lib().ptts_tokenizer_vocab_size(self.h))
+
+    def encode(self, text: str) -> list:
+        raw = text.encode("utf-8")
+        ids = np.zeros(max(16, len(raw) + 2), np.int64)
+        n = int(lib().ptts_tokenizer_encode(self.h, raw, len(raw), _ip(ids), ids.size))
+        if n < 0:
+            raise PttsError(PTTS_EINVAL, lib().ptts_last_error().decode())
+        if n > ids.size:
+            ids = np.zeros(n, np.int64)
+            n = int(lib().ptts_tokenizer_encode(self.h, raw, len(raw), _ip(ids), ids.size))
+        return [int(x) for x in ids[:n]]
+
+    __call__ = encode
+
+    def close(self):
+        if self.h:
+            lib().ptts_tokenizer_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def nfkc(text: str) -> str:
+    """NFKC as the tokenizer applies it (ptts_text_nfkc: generated Unicode tables)."""
+    raw = text.encode("utf-8")
+    L = lib()
+    L.ptts_text_nfkc.argtypes = [C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, C.POINTER(C.c_int64)]
+    n = C.c_int64(0)
+    buf = C.create_string_buffer(max(16, 20 * len(raw) + 16))   # one code point can expand to 18 (U+FDFA)
+    _check(L.ptts_text_nfkc(raw, len(raw), buf, len(buf), C.byref(n)))
+    return buf.raw[: n.value].decode("utf-8")
+
+
 class _ChunkInfo(C.Structure):
     _fields_ = [("text", C.c_void_p), ("text_len", C.c_int64), ("token_ids", _IP), ("n_tokens", C.c_int64), ("num_words", C.c_int32),
                 ("max_frames", C.c_int32), ("frames_after_eos", C.c_int32), ("reserved", C.c_int32)]
@@ -866,10 +929,13 @@ def prepare_chunks(text: str, encode: Callable[[str], Sequence[int]], max_tokens
             ids[i] = int(v)
         return len(got)
 
-    fn = _ENCODE_FN(cb)
     raw = text.encode("utf-8", "surrogatepass")
     h = C.c_void_p()
-    _check(L.ptts_text_chunks(raw, len(raw), fn, None, max_tokens, frame_rate, C.byref(h)))
+    if isinstance(encode, Tokenizer):   # the library's own encoder: no callback into Python (encode == NULL, user = tokenizer)
+        _check(L.ptts_text_chunks(raw, len(raw), C.cast(None, _ENCODE_FN), encode.h, max_tokens, frame_rate, C.byref(h)))
+    else:
+        fn = _ENCODE_FN(cb)
+        _check(L.ptts_text_chunks(raw, len(raw), fn, None, max_tokens, frame_rate, C.byref(h)))
     try:
         out = []
         for i in range(L.ptts_chunks_count(h)):

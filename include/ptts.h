@@ -176,6 +176,23 @@ int32_t ptts_text_frames_after_eos(int64_t num_words);                          
 int  ptts_text_prepare(const char* utf8, int64_t len, char* out, int64_t cap, int64_t* out_len);
 /* Encoder callback: writes up to cap ids and returns the count (> cap: called again with room), < 0: error. */
 typedef int64_t (*ptts_encode_fn)(void* user, const char* utf8, int64_t len, int64_t* ids, int64_t cap);
+
+/* SentencePiece unigram encoder (tokenizer.NewSentencePieceTokenizer / Tokenizer.Encode, internal/tokenizer/sentencepiece.go:19-40;
+ * algorithm: internal/tokenizer/sentencepiece_bytes_wasm.go = go-sentencepiece-encoder v1.1.1): reads the pieces of a
+ * SentencePiece ModelProto (`tokenizer.model`), normalises (control characters dropped, White_Space -> ' ', NFKC), prepends and
+ * substitutes U+2581, Viterbi over the piece trie, consecutive unknowns merged. */
+typedef struct ptts_tokenizer ptts_tokenizer;
+int     ptts_tokenizer_open(const char* model_path, ptts_tokenizer** out);
+int     ptts_tokenizer_open_bytes(const void* data, size_t len, ptts_tokenizer** out);
+void    ptts_tokenizer_free(ptts_tokenizer* t);
+int64_t ptts_tokenizer_vocab_size(const ptts_tokenizer* t);
+/* Encode: writes up to cap ids, returns the count (> cap: call again with room; an empty text gives 0), < 0 on error */
+int64_t ptts_tokenizer_encode(const ptts_tokenizer* t, const char* utf8, int64_t len, int64_t* ids, int64_t cap);
+/* the same as a ptts_encode_fn (user = the ptts_tokenizer): ptts_text_chunks(text, len, ptts_tokenizer_encode_cb, tok, ...);
+ * ptts_text_chunks also takes encode == NULL with user = a ptts_tokenizer as "use the built-in encoder" */
+int64_t ptts_tokenizer_encode_cb(void* user, const char* utf8, int64_t len, int64_t* ids, int64_t cap);
+/* NFKC as the tokenizer applies it (generated Unicode tables) */
+int     ptts_text_nfkc(const char* utf8, int64_t len, char* out, int64_t cap, int64_t* out_len);
 typedef struct ptts_chunks ptts_chunks;
 typedef struct ptts_chunk_info {
     const char* text; int64_t text_len;            /* PrepareText of the joined sentences */
