@@ -37,7 +37,7 @@ ptts_opts resolve_opts(const ptts_opts* o) {
     ptts_default_opts(&r);
     if (o) r = *o;
     if (r.max_batch <= 0) r.max_batch = 64;
-    if (r.weights != PTTS_WEIGHTS_F32 && r.weights != PTTS_WEIGHTS_BF16) throw Error(PTTS_EINVAL, "ptts-hip: unknown weights mode");
+    if (r.weights != PTTS_WEIGHTS_F32 && r.weights != PTTS_WEIGHTS_BF16 && r.weights != PTTS_WEIGHTS_INT8) throw Error(PTTS_EINVAL, "ptts-hip: unknown weights mode");
     if (r.kv != PTTS_KV_F32 && r.kv != PTTS_KV_BF16) throw Error(PTTS_EINVAL, "ptts-hip: unknown kv mode");
     return r;
 }
@@ -593,6 +593,31 @@ int ptts_decode_latents(ptts_model* h, const float* latents, int32_t n_utt, int3
     return ptts_decode_stages(h, latents, n_utt, frames, pcm, mimi_latent, nullptr);
 }
 
+int ptts_speaker_project(ptts_model* h, const float* latent, int64_t frames, float* out) {
+    return guard([&] {
+        if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
+        Model& m = *h->m;
+        const Lin& l = m.d.speaker_proj;
+        if (l.w == NONE) throw Error(PTTS_EFORMAT, "load speaker_proj_weight: tensor not found in the model weights");
+        if (!latent || !out || frames <= 0) throw Error(PTTS_EINVAL, strfmt("latent shape must be [1,T,%d], got [1 %lld %d]", l.in, (long long)frames, l.in));
+        std::lock_guard<std::mutex> lock(m.mu);
+        m.use_device();
+        const size_t ni = (size_t)frames * l.in, no = (size_t)frames * l.out;
+        DevBuf& io = m.work(8, (ni + no) * sizeof(float));
+        float* di = io.as<float>();
+        float* dout = di + ni;
+        PTTS_HIP(hipMemcpyAsync(di, latent, ni * sizeof(float), hipMemcpyHostToDevice, m.stream));
+        GemmArgs g;
+        g.A = di; g.amap = RowMap{l.in, 0, 0};
+        g.W = m.arena + l.w; g.w_bf16 = 0; g.ldw = l.in;
+        g.C = dout; g.cmap = RowMap{l.out, 0, 0};
+        g.M = (int)frames; g.N = l.out; g.K = l.in;
+        launch_gemm(g, m.stream);
+        PTTS_HIP(hipMemcpyAsync(out, dout, no * sizeof(float), hipMemcpyDeviceToHost, m.stream));
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
 int ptts_noise_rows(ptts_model* h, uint64_t seed, float temperature, int32_t rows, float* out) {
     return guard([&] {
         if (!h || !h->m || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
@@ -641,6 +666,7 @@ int ptts_flow_direction(ptts_model* h, const float* c, float sv, float tv, const
             GemmArgs g;
             g.A = A; g.amap = RowMap{lda, 0, 0};
             g.W = m.arena + l.w; g.w_bf16 = l.bf16; g.ldw = l.in; g.bias = m.at<float>(l.b);
+            g.wt_i8 = l.wt_i8; g.wscale = m.at<float>(l.wscale);
             g.C = Cc; g.cmap = RowMap{ldc, 0, 0};
             g.M = B; g.N = l.out; g.K = l.in;
             return g;

@@ -38,6 +38,7 @@ struct GemmArgs {
     const float* A = nullptr; RowMap amap;
     const void*  W = nullptr; int w_bf16 = 0; int64_t ldw = 0;
     const void*  Wt = nullptr;       // fragment-ordered copy of W for the AR-step kernel (model.cpp add_tiled), optional
+    int wt_i8 = 0; const float* wscale = nullptr;   // Wt holds per-row-scaled int8 (PTTS_WEIGHTS_INT8); wscale: [N] row scales
     const float* bias = nullptr;     // [N] or null
     const float* addvec = nullptr;   // [N] or null (EPI_SILU only)
     float*       C = nullptr; RowMap cmap;

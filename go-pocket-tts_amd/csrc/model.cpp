@@ -14,8 +14,9 @@ namespace {
 struct Walker {
     const StFile& f;
     Desc& d;
-    bool bf16w;
+    bool bf16w;     // matrices are held as bf16 (PTTS_WEIGHTS_BF16 and PTTS_WEIGHTS_INT8: everything the AR step does not stream)
     uint8_t* host;  // null while planning
+    bool i8w = false;   // PTTS_WEIGHTS_INT8: the matrices the AR step streams are per-row-scaled int8 in the step kernel's fragment order
     size_t cur = 0;
 
     size_t reserve(size_t bytes) {
@@ -58,7 +59,78 @@ struct Walker {
     // Fragment-ordered copy for the AR-step kernel: per (16-row tile, 128-deep super-step) one block of WV KiB in which
     // MFMA step s of lane l reads 16 contiguous bytes at [s][l]: W[tile*16 + (l & 15)][ss*128 + (l >> 4)*32 + s*E .. +E),
     // E = 8 (bf16) or 4 (f32).  Every wave-level weight load of the step is then one contiguous 1-KiB burst.
+    // ---- PTTS_WEIGHTS_INT8: weight-only int8 for the matrices the AR step streams ----
+    // Row n of W becomes q[n][k] in [-127, 127] and a scale s[n] = max_k |W[n][k]| / 127 (1 for an all-zero row);
+    // q = rint(W / s) (ties to even), the effective weight is W^ = q * s.  The step kernel streams q (1 byte per weight, stored
+    // offset-binary q + 128, in its fragment order) and multiplies by s[n] in the epilogue; everything else that touches the
+    // matrix (prefill GEMMs, the 32-wide linears of k_step_begin) reads a row-major f32 copy of W^, so that the whole
+    // model computes with ONE set of weights -- the ones an f32 oracle is given in the parity tests.
+    static void quantize_rows(std::vector<float>& rm, size_t out, size_t in, std::vector<float>& scale, std::vector<int8_t>& q) {
+        scale.assign(out, 1.0f);
+        q.assign(out * in, 0);
+        for (size_t n = 0; n < out; n++) {
+            float mx = 0.0f;
+            for (size_t k = 0; k < in; k++) mx = std::max(mx, std::fabs(rm[n * in + k]));
+            const float s = mx > 0.0f ? mx / 127.0f : 1.0f;
+            scale[n] = s;
+            for (size_t k = 0; k < in; k++) {
+                float v = std::nearbyint(rm[n * in + k] / s);
+                v = std::min(127.0f, std::max(-127.0f, v));
+                q[n * in + k] = (int8_t)v;
+                rm[n * in + k] = v * s;
+            }
+        }
+    }
+    // tiled int8 copy + scales of a row-major matrix (rm is replaced by W^).  Layout: per (16-row tile, 128-deep super-step) 2 KiB:
+    // load u (0, 1) of lane l is 16 bytes = MFMA steps 2u and 2u + 1, byte j -> k = ss*128 + (l >> 4)*32 + (2u + j/8)*8 + j%8
+    void add_tiled_i8(Lin& l, std::vector<float>* rm) {
+        const size_t nt = ((size_t)l.out + 15) / 16, nss = ((size_t)l.in + 127) / 128;
+        l.wt = reserve(nt * nss * 2048);
+        l.wscale = reserve((size_t)l.out * 4);
+        l.wt_i8 = 1;
+        if (!host) return;
+        std::vector<float> scale;
+        std::vector<int8_t> q;
+        quantize_rows(*rm, (size_t)l.out, (size_t)l.in, scale, q);
+        std::memcpy(host + l.wscale, scale.data(), scale.size() * 4);
+        uint8_t* dst = host + l.wt;
+        for (size_t t = 0; t < nt; t++)
+            for (size_t ss = 0; ss < nss; ss++)
+                for (int u = 0; u < 2; u++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 16; j++) {
+                            const size_t n = t * 16 + (size_t)(lane & 15), k = ss * 128 + (size_t)(lane >> 4) * 32 + (size_t)(2 * u + j / 8) * 8 + (size_t)(j % 8);
+                            const int v = (n < (size_t)l.out && k < (size_t)l.in) ? q[n * l.in + k] : 0;
+                            dst[((((t * nss + ss) * 2 + u) * 64 + lane) * 16) + j] = (uint8_t)(v + 128);
+                        }
+    }
+    // a matrix the AR step streams, with its row-major copy (own_rowmajor) or only the tiled one (a stack of matrices whose
+    // rows already exist row-major elsewhere)
+    void add_step_matrix(Lin& l, const std::function<void(float*)>& fill_rowmajor, bool own_rowmajor) {
+        const size_t count = (size_t)l.out * l.in;
+        if (!i8w) {
+            if (own_rowmajor) l.w = add_mat(count, fill_rowmajor, &l.bf16);
+            add_tiled(l, fill_rowmajor);
+            return;
+        }
+        std::vector<float> rm;
+        if (host) { rm.resize(count); fill_rowmajor(rm.data()); }
+        add_tiled_i8(l, &rm);   // rm -> W^
+        if (own_rowmajor) {
+            l.bf16 = 0;
+            l.w = reserve(count * 4);
+            if (host) std::memcpy(host + l.w, rm.data(), count * 4);
+            d.n_params += (int64_t)count;
+        }
+    }
+
     void add_tiled(Lin& l, const std::function<void(float*)>& fill_rowmajor) {
+        if (i8w) {
+            std::vector<float> rm;
+            if (host) { rm.resize((size_t)l.out * l.in); fill_rowmajor(rm.data()); }
+            add_tiled_i8(l, &rm);
+            return;
+        }
         const int E = bf16w ? 8 : 4, WV = bf16w ? 4 : 8;
         const size_t nt = ((size_t)l.out + 15) / 16, nss = ((size_t)l.in + 127) / 128;
         const size_t count = nt * nss * 16 * 128;
@@ -105,9 +177,23 @@ struct Walker {
                     }
     }
     Lin step_linear(const std::string& name, bool with_bias) {
-        Lin l = linear(name, with_bias);
+        if (!i8w) {
+            Lin l = linear(name, with_bias);
+            const std::string wn = name + ".weight";
+            add_tiled(l, [&](float* dst) { f.decode_f32(wn, dst); });
+            return l;
+        }
+        Lin l;
         const std::string wn = name + ".weight";
-        add_tiled(l, [&](float* dst) { f.decode_f32(wn, dst); });
+        expect_rank(wn, 2);
+        l.out = (int)shape(wn)[0];
+        l.in = (int)shape(wn)[1];
+        add_step_matrix(l, [&](float* dst) { f.decode_f32(wn, dst); }, true);
+        if (with_bias && has(name + ".bias")) {
+            const std::string bn = name + ".bias";
+            if (shape(bn).size() != 1 || shape(bn)[0] != l.out) throw Error(PTTS_EFORMAT, strfmt("native: linear \"%s\" bias shape incompatible with weight", name.c_str()));
+            l.b = add_f32((size_t)l.out, [&](float* dst) { f.decode_f32(bn, dst); });
+        }
         return l;
     }
 
@@ -298,14 +384,10 @@ struct Walker {
             }
             d.ada_all.out = rows;
             d.ada_all.in = C;
-            d.ada_all.w = add_mat((size_t)rows * C, [&](float* dst) {
+            add_step_matrix(d.ada_all, [&](float* dst) {
                 size_t o = 0;
                 for (auto& n : names) { f.decode_f32(n + ".weight", dst + o); o += (size_t)f.at(n + ".weight").count(); }
-            }, &d.ada_all.bf16);
-            add_tiled(d.ada_all, [&](float* dst) {
-                size_t o = 0;
-                for (auto& n : names) { f.decode_f32(n + ".weight", dst + o); o += (size_t)f.at(n + ".weight").count(); }
-            });
+            }, true);
             d.ada_all.b = add_f32((size_t)rows, [&](float* dst) {
                 size_t o = 0;
                 for (auto& n : names) {
@@ -317,6 +399,18 @@ struct Walker {
             });
         }
         d.final_linear = step_linear(fn + "final_layer.linear", true);
+        // speaker conditioning projection (onnx/voice_encode.go:160-202: either name; [VoiceEmbeddingDim, mimiEncoderLatentDim]), optional
+        for (const char* nm : {"flow_lm.speaker_proj_weight", "condition_provider.conditioners.speaker_wavs.output_proj.weight"}) {
+            if (!has(nm) || d.speaker_proj.w != NONE) continue;
+            expect_rank(nm, 2);
+            const std::string name = nm;
+            d.speaker_proj.out = (int)shape(name)[0];
+            d.speaker_proj.in = (int)shape(name)[1];
+            // held in f32: the reference multiplies the f32 tensor as it is (projectSpeakerConditioning)
+            d.speaker_proj.w = add_f32((size_t)d.speaker_proj.out * d.speaker_proj.in, [this, name](float* dst) { f.decode_f32(name, dst); });
+            d.speaker_proj.bf16 = 0;
+            d.n_params += (int64_t)d.speaker_proj.out * d.speaker_proj.in;
+        }
         // ---------------- mimi ----------------
         const std::string mi = "mimi.";
         {
@@ -431,13 +525,13 @@ struct Walker {
 }  // namespace
 
 void plan_build(Plan& p) {
-    Walker w{p.file, p.desc, p.opts.weights == PTTS_WEIGHTS_BF16, nullptr};
+    Walker w{p.file, p.desc, p.opts.weights != PTTS_WEIGHTS_F32, nullptr, p.opts.weights == PTTS_WEIGHTS_INT8};
     w.run();
 }
 
 void plan_fill(const Plan& p, uint8_t* host) {
     Desc scratch = p.desc;
-    Walker w{p.file, scratch, p.opts.weights == PTTS_WEIGHTS_BF16, host};
+    Walker w{p.file, scratch, p.opts.weights != PTTS_WEIGHTS_F32, host, p.opts.weights == PTTS_WEIGHTS_INT8};
     w.run();
     if (scratch.total_bytes != p.desc.total_bytes) throw Error(PTTS_EFORMAT, "ptts-hip: arena layout changed between plan and fill");
 }

@@ -18,6 +18,7 @@ constexpr int ROPE_SEQ = 8192;  // flow_transformer.go:505, mimi.go:498
 struct Lin {   // linear.go:11-16 (also a convolution expressed as a GEMM)
     size_t w = NONE, b = NONE;
     size_t wt = NONE;   // second copy in the AR-step kernel's fragment order (skinny.hip), NONE for weights the step never streams
+    size_t wscale = NONE; int wt_i8 = 0;   // PTTS_WEIGHTS_INT8: wt holds per-row-scaled int8 (q + 128), wscale the f32 scale of every row
     size_t wf = NONE, wf_lo = NONE;   // copy in 16x16x32 MFMA fragment order for the fused SEANet block (resblock.hip); lo plane: f32 weights only
     int in = 0, out = 0, bf16 = 0;
 };
@@ -38,6 +39,7 @@ struct Desc {
     int flow_dim = 0, flow_depth = 0, nfreq = 0;
     struct TE { size_t freqs = NONE, alpha = NONE; Lin l1, l2; } te[2];
     Lin cond_embed, input_proj, ada_all, final_linear;
+    Lin speaker_proj;   // optional: flow_lm.speaker_proj_weight [d_model, 512] (voice cloning: Mimi-encoder latents -> voice embedding)
     Lin cond_eos;   // cond_embed with out_eos stacked as its last row: both read the out_norm rows, one launch (runtime.cpp step_core)
     struct RB { Norm ln; Lin mlp0, mlp2; } rb[MAX_LAYERS];
     // mimi (mimi.go:16-34,528-544)

@@ -18,6 +18,7 @@ static GemmArgs mk(const Model& m, const float* A, RowMap am, const Lin& l, floa
     g.A = A; g.amap = am;
     g.W = m.arena + l.w; g.w_bf16 = l.bf16; g.ldw = l.in;
     g.Wt = l.wt == NONE ? nullptr : m.arena + l.wt;
+    g.wt_i8 = l.wt_i8; g.wscale = m.at<float>(l.wscale);
     g.bias = m.at<float>(l.b);
     g.C = C; g.cmap = cm;
     g.M = M; g.N = l.out; g.K = l.in;
@@ -480,8 +481,9 @@ static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = Skinny
         if (!sk) PTTS_HIP(hipEventRecord(p.ev[p.used + 1], st));
         p.used += 2;
         p.launches++;
-        p.bytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4) + (double)g.M * g.K * 4 * (1 + fu.psplit) + (double)g.M * g.N * 4 * (splitk > 1 ? splitk : 1);
-        p.wbytes += (double)g.N * g.K * (g.w_bf16 ? 2 : 4);
+        const int wbytes = (sk && g.wt_i8) ? 1 : (g.w_bf16 ? 2 : 4);
+        p.bytes += (double)g.N * g.K * wbytes + (double)g.M * g.K * 4 * (1 + fu.psplit) + (double)g.M * g.N * 4 * (splitk > 1 ? splitk : 1);
+        p.wbytes += (double)g.N * g.K * wbytes;
     }
 }
 
@@ -621,7 +623,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         }
         {
             GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
-            const int S = pick_split(B, D, d.ffn, g2.w_bf16 != 0);
+            const int S = pick_split(B, D, d.ffn, g2.w_bf16 != 0 || g2.wt_i8 != 0);
             if (S > 1 && skinny_supported(g2, S)) {
                 step_gemm(m, g2, SkinnyFuse{}, S, b.partial.as<float>());
                 pend.partial = b.partial.as<float>(); pend.splitk = S; pend.pstride = (int64_t)B * D; pend.bias = m.at<float>(L.l2.b);

@@ -66,7 +66,9 @@ constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_TWO 
 // launches whose 64-column grid would leave most of the chip idle: batch <= 16, the reference's own batch-1 case)
 // FIN: the launch carries the AR step's bookkeeping (SkinnyFuse::fin) -- a template parameter so that the other variants do
 // not hold its eight registers (the fused-prologue variants sit at the 128-register limit of a 16-wave block)
-template <bool WBF16, bool STAMP, int PRO, int NJ, int CG, bool FIN = false>
+// WT: how the weights are stored -- 0: f32, 1: bf16, 2: per-row-scaled int8 (offset-binary bytes; converted to bf16 in registers,
+// which is exact for [-127, 127]; the row scale is applied to the sums in the epilogue)
+template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false>
 __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_m, int p_n, int p_k, int splitk, GemmArgs a, SkinnyFuse fu,
                                                  float* partial, unsigned long long* stamps) {
     // The seven leading scalars (copies of a.Wt, a.A, a.amap.ld, a.M, a.N, a.K, and the split) are what the weight and
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 #define SK_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
     SK_STAMP(7);
-    constexpr int WV = WBF16 ? 4 : 8;          // 16-byte weight loads per lane per super-step
+    constexpr int WV = WT == 2 ? 2 : (WT == 1 ? 4 : 8);   // 16-byte weight loads per lane per super-step
     // LDS image: row r (0..15) = 2048 B = 128 chunks of 16 B; chunk c is stored at c ^ r, so the 16 lanes that read
     // the same logical chunk of 16 different rows hit 16 different bank groups
     constexpr int RB = NJ > 4 ? 4096 : 2048, CMASK = RB / 16 - 1;   // bytes and 16-byte chunks (- 1) per image row
@@ -119,6 +121,8 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     // ---- epilogue operands: requested now by the waves that will store (K quarter 0), consumed after the K reduction ----
     // (an element of R that aliases C is read and written by the same lane only)
     float e_bias = 0.f, e_addv = 0.f, e_scl = 1.f, e_r[4] = {0.f, 0.f, 0.f, 0.f}, e_g[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_ws = 1.0f;   // int8 weights: the scale of this lane's output column
+    if constexpr (WT == 2) { if (kq4 == 0) e_ws = a.wscale[n_ok ? n : 0]; }
     if (kq4 == 0 && splitk <= 1) {
         const int nc = n_ok ? n : 0;
         if (a.bias) e_bias = a.bias[nc];
@@ -331,7 +335,23 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             Frag8 xh, xl;
             xh.q = *reinterpret_cast<const uint4*>(&Xh[off]);
             xl.q = *reinterpret_cast<const uint4*>(&Xl[off]);
-            if constexpr (WBF16) {
+            if constexpr (WT == 2) {
+                // 8 offset-binary bytes -> 8 bf16: (float)byte - 128 is an integer in [-127, 127], exact in bf16
+                const uint4 r = w[t][s >> 1];
+                const unsigned d0 = (s & 1) ? r.z : r.x, d1 = (s & 1) ? r.w : r.y;
+                Frag8 wv;
+                f32x2 p;
+                p = f32x2{(float)(d0 & 0xffu), (float)((d0 >> 8) & 0xffu)} - f32x2{128.f, 128.f};
+                { bf16x2 b = __builtin_convertvector(p, bf16x2); wv.u[0] = *reinterpret_cast<unsigned*>(&b); }
+                p = f32x2{(float)((d0 >> 16) & 0xffu), (float)(d0 >> 24)} - f32x2{128.f, 128.f};
+                { bf16x2 b = __builtin_convertvector(p, bf16x2); wv.u[1] = *reinterpret_cast<unsigned*>(&b); }
+                p = f32x2{(float)(d1 & 0xffu), (float)((d1 >> 8) & 0xffu)} - f32x2{128.f, 128.f};
+                { bf16x2 b = __builtin_convertvector(p, bf16x2); wv.u[2] = *reinterpret_cast<unsigned*>(&b); }
+                p = f32x2{(float)((d1 >> 16) & 0xffu), (float)(d1 >> 24)} - f32x2{128.f, 128.f};
+                { bf16x2 b = __builtin_convertvector(p, bf16x2); wv.u[3] = *reinterpret_cast<unsigned*>(&b); }
+                acc_h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wv.v, acc_h, 0, 0, 0);
+                acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xl.v, wv.v, acc_l, 0, 0, 0);
+            } else if constexpr (WT == 1) {
                 Frag8 wv;
                 wv.q = w[t][s];
                 acc_h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xh.v, wv.v, acc_h, 0, 0, 0);
@@ -371,7 +391,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             int m = m0 + q * 4 + reg;
-            if (m < p_m) partial[((int64_t)z * p_m + m) * p_n + n] = acc[reg];
+            if (m < p_m) partial[((int64_t)z * p_m + m) * p_n + n] = acc[reg] * e_ws;
         }
         return;
     }
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     for (int reg = 0; reg < 4; reg++) {
         int m = m0 + q * 4 + reg;
         if (m >= p_m) continue;
-        float v = acc[reg] + e_bias;
+        float v = acc[reg] * e_ws + e_bias;
         int64_t co = (int64_t)m * a.cmap.ld + n;
         if (a.tail && n == p_n - 1) { a.tail[m] = v; continue; }
         switch (a.epi) {
@@ -428,7 +448,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 bool skinny_supported(const GemmArgs& a, int splitk) {
     if (splitk < 1) splitk = 1;
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= (splitk > 1 && a.w_bf16 ? SK_KMAX2 : SK_KMAX) && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
+    return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= (splitk > 1 && (a.w_bf16 || a.wt_i8) ? SK_KMAX2 : SK_KMAX) && (!a.wt_i8 || a.wscale) && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
            a.amap.ld % 4 == 0 && aligned16(a.A) && aligned16(a.W) && a.ldw % 8 == 0 && a.aop == AOP_NONE;
 }
 
@@ -443,7 +463,7 @@ thread_local hipEvent_t g_skinny_ev[2] = {nullptr, nullptr};   // measurement pa
 thread_local unsigned long long* g_skinny_stamps = nullptr;   // debug (ptts_debug_skinny_stamps)
 thread_local SkinnyStampLog* g_skinny_stamp_log = nullptr;    // debug (ptts_debug_step_stamps)
 
-template <bool WBF16, int PRO, int NJ, int CG>
+template <int WBF16, int PRO, int NJ, int CG>
 static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
     dim3 grid((a.N + 16 * CG - 1) / (16 * CG), (a.M + 15) / 16, splitk);
     if constexpr (PRO == (PRO_LN | PRO_MOD) && NJ == 2 && CG == 4) {
@@ -473,7 +493,7 @@ static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
     else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
 }
 
-template <bool WBF16, int PRO, int NJ>
+template <int WBF16, int PRO, int NJ>
 static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 /*grid*/, hipStream_t stream) {
     // narrow blocks when the 64-column grid would occupy fewer than half of the 256 CUs
     const int blocks64 = ((a.N + 63) / 64) * ((a.M + 15) / 16) * splitk;
@@ -481,16 +501,16 @@ static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
     else launch_cg<WBF16, PRO, NJ, 4>(a, fu, splitk, partial, stream);
 }
 
-template <bool WBF16, int PRO>
+template <int WBF16, int PRO>
 static void launch_pro(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
     if (kslice <= 512) launch_nj<WBF16, PRO, 2>(a, fu, splitk, partial, grid, stream);
     else if (kslice <= SK_KMAX) launch_nj<WBF16, PRO, 4>(a, fu, splitk, partial, grid, stream);
-    else if constexpr (PRO == 0 && WBF16) launch_cg<WBF16, 0, 8, 2>(a, fu, splitk, partial, stream);   // 2048-deep slices: 32-column blocks x 8 K parts
+    else if constexpr (PRO == 0 && WBF16 != 0) launch_cg<WBF16, 0, 8, 2>(a, fu, splitk, partial, stream);   // 2048-deep slices: 32-column blocks x 8 K parts
     else throw Error(PTTS_EINVAL, "ptts-hip: internal: K slice too deep for this variant of the step kernel");
 }
 
-template <bool WBF16>
+template <int WBF16>
 static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
     const int pro = (fu.ln ? PRO_LN : 0) | ((fu.ln && fu.ln_w) ? PRO_AFFINE : 0) | ((fu.ln && fu.scale) ? PRO_MOD : 0) | (fu.partial ? PRO_PARTIAL : 0);
     switch (pro) {
@@ -512,8 +532,9 @@ void launch_skinny(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* p
     if (a.M <= 0 || a.N <= 0) return;
     note_launch("k_skinny");
     dim3 grid((a.N + 63) / 64, (a.M + 15) / 16, splitk);
-    if (a.w_bf16) launch_w<true>(a, fu, splitk, partial, grid, stream);
-    else launch_w<false>(a, fu, splitk, partial, grid, stream);
+    if (a.wt_i8) launch_w<2>(a, fu, splitk, partial, grid, stream);
+    else if (a.w_bf16) launch_w<1>(a, fu, splitk, partial, grid, stream);
+    else launch_w<0>(a, fu, splitk, partial, grid, stream);
 }
 
 }  // namespace ptts

@@ -22,7 +22,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libptts_hip.so")
 
 PTTS_OK, PTTS_EINVAL, PTTS_EIO, PTTS_EFORMAT, PTTS_ENODEVICE, PTTS_ECANCELLED, PTTS_ENOMEM = range(7)
-WEIGHTS_F32, WEIGHTS_BF16 = 0, 1
+WEIGHTS_F32, WEIGHTS_BF16, WEIGHTS_INT8 = 0, 1, 2
 KV_F32, KV_BF16 = 0, 1
 
 _FP = C.POINTER(C.c_float)
@@ -89,7 +89,7 @@ ABI_SYMBOLS = [
     "ptts_plan_create", "ptts_plan_create_bytes", "ptts_plan_arena_bytes", "ptts_model_open_planned", "ptts_plan_free",
     "ptts_generate", "ptts_free_result", "ptts_text_embeddings", "ptts_batch_new", "ptts_batch_free", "ptts_batch_reset",
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
-    "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_noise_rows", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
+    "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_noise_rows", "ptts_speaker_project", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
@@ -399,6 +399,16 @@ class Model:
         xf = np.empty((n, fr * self.info.steps_per_latent, self.info.mimi_dim), np.float32)
         _check(lib().ptts_decode_stages(self.h, _fp(lat), n, fr, _fp(pcm), _fp(ml), _fp(xf)))
         return pcm, ml, xf
+
+    def speaker_project(self, latent) -> np.ndarray:
+        """projectSpeakerConditioning (onnx/voice_encode.go:119-158): Mimi-encoder latents [T, 512] -> voice embedding [T, d_model]."""
+        lat = _f32(latent)
+        lat = lat.reshape(-1, lat.shape[-1])
+        out = np.empty((lat.shape[0], self.info.d_model), np.float32)
+        L = lib()
+        L.ptts_speaker_project.argtypes = [C.c_void_p, _FP, C.c_int64, _FP]
+        _check(L.ptts_speaker_project(self.h, _fp(lat), lat.shape[0], _fp(out)))
+        return out
 
     def noise_rows(self, seed: int, temperature: float, rows: int) -> np.ndarray:
         """The device draw of makeGaussianNoise (flow_lm.go:386-408) a request with (noise_seed, temperature) consumes."""

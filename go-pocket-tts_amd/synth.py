@@ -34,6 +34,7 @@ class SynthConfig:
     mimi_ffn: int = 2048
     n_filters: int = 64        # SEANet ladder 8f -> 4f -> 2f -> f -> 1
     input_linear_bias: bool = False
+    speaker_proj: bool = False  # also write flow_lm.speaker_proj_weight [d_model, 512]
     layer_scale: float = 0.01  # Mimi layer_scale_{1,2}; ~1 makes the decoder transformer's branches count in full
 
     @staticmethod
@@ -143,6 +144,8 @@ def make_checkpoint(cfg: SynthConfig = SynthConfig(), seed: int = 1234) -> dict[
         lin(p + ".mlp.2", C, C, True)
         lin(p + ".adaLN_modulation.1", 3 * C, C, True, gain=0.5)
     lin("flow_lm.flow_net.final_layer.linear", cfg.ldim, C, True)
+    if cfg.speaker_proj:   # voice cloning: Mimi-encoder latents [T, 512] -> [T, d_model] (onnx/voice_encode.go:174-188)
+        t["flow_lm.speaker_proj_weight"] = (rng.standard_normal((D, 512)) / np.sqrt(512.0)).astype(np.float32)
     lin("flow_lm.flow_net.final_layer.adaLN_modulation.1", 2 * C, C, True, gain=0.5)
 
     M = cfg.mimi_dim
@@ -181,6 +184,42 @@ def make_checkpoint(cfg: SynthConfig = SynthConfig(), seed: int = 1234) -> dict[
         conv(f"mimi.decoder.model.{idx_rb}.block.3.conv", ch[j + 1], ch[j + 1] // 2, 1)
     conv("mimi.decoder.model.11.conv", 1, ch[3], 3)
     return t
+
+
+INT8_STEP_MATRICES = ("self_attn.in_proj.weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight")
+
+
+def int8_step_weight_names(tensors: dict[str, np.ndarray]) -> list[str]:
+    """The matrices PTTS_WEIGHTS_INT8 quantizes: everything the AR step streams (model.cpp step_linear / ada_all)."""
+    names = []
+    for k in tensors:
+        if not k.endswith(".weight") or tensors[k].ndim != 2:
+            continue
+        if k.startswith("flow_lm.transformer.layers.") and k.endswith(INT8_STEP_MATRICES):
+            names.append(k)
+        elif k in ("flow_lm.input_linear.weight", "flow_lm.out_eos.weight"):
+            names.append(k)
+        elif k.startswith("flow_lm.flow_net.") and ".time_embed." not in k:
+            names.append(k)
+    return sorted(names)
+
+
+def quantize_int8_rows(w: np.ndarray) -> np.ndarray:
+    """W^ = q * s with s = max|row| / 127 (1 for a zero row), q = rint(W / s) clipped to [-127, 127] -- the same f32 arithmetic as
+    model.cpp quantize_rows, so the result is bit-identical to the weights the library computes with."""
+    w = w.astype(np.float32)
+    mx = np.abs(w).max(axis=1)
+    s = np.where(mx > 0, mx / np.float32(127.0), np.float32(1.0)).astype(np.float32)
+    q = np.clip(np.rint(w / s[:, None]), -127, 127).astype(np.float32)
+    return (q * s[:, None]).astype(np.float32)
+
+
+def dequantized_int8_checkpoint(tensors: dict[str, np.ndarray]) -> dict[str, np.ndarray]:
+    """The checkpoint an f32 reference must be given to compute with the weights of PTTS_WEIGHTS_INT8."""
+    out = dict(tensors)
+    for k in int8_step_weight_names(tensors):
+        out[k] = quantize_int8_rows(tensors[k])
+    return out
 
 
 def quantize_like_file(tensors: dict[str, np.ndarray], dtype: str) -> dict[str, np.ndarray]:

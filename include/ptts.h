@@ -41,6 +41,10 @@ extern "C" {
 /* how weights are held in HBM */
 #define PTTS_WEIGHTS_F32   0  /* as the reference holds them (every dtype decoded to f32, store.go:339-395) */
 #define PTTS_WEIGHTS_BF16  1  /* 2 bytes/param; exact when the file itself is BF16 */
+#define PTTS_WEIGHTS_INT8  2  /* weight-only int8 for every matrix the AR step streams (1 byte/param, per-row f32 scale: q = rint(W / s),
+                               * s = max|row| / 127; the effective weights q*s are used consistently by prefill and step); the rest as
+                               * PTTS_WEIGHTS_BF16.  Not a reference mode (the reference's int8 is ONNX quantize_dynamic,
+                               * scripts/export_onnx.py:319-331): tolerance stated against the f32 oracle in tests/test_gpu_int8.py */
 /* KV-cache element type */
 #define PTTS_KV_F32   0
 #define PTTS_KV_BF16  1
@@ -188,7 +192,7 @@ void    ptts_tokenizer_free(ptts_tokenizer* t);
 int64_t ptts_tokenizer_vocab_size(const ptts_tokenizer* t);
 /* Encode: writes up to cap ids, returns the count (> cap: call again with room; an empty text gives 0), < 0 on error */
 int64_t ptts_tokenizer_encode(const ptts_tokenizer* t, const char* utf8, int64_t len, int64_t* ids, int64_t cap);
-/* the same as a ptts_encode_fn (user = the ptts_tokenizer): ptts_text_chunks(text, len, ptts_tokenizer_encode_cb, tok, ...);
+/* the same with the signature of the encoder callback, user = the ptts_tokenizer: ptts_text_chunks(text, len, ptts_tokenizer_encode_cb, tok, ...);
  * ptts_text_chunks also takes encode == NULL with user = a ptts_tokenizer as "use the built-in encoder" */
 int64_t ptts_tokenizer_encode_cb(void* user, const char* utf8, int64_t len, int64_t* ids, int64_t cap);
 /* NFKC as the tokenizer applies it (generated Unicode tables) */
@@ -279,6 +283,12 @@ int  ptts_decode_latents(ptts_model* m, const float* latents, int32_t n_utt, int
  * mimiTransformerLayer loop (mimi.go:733-748) -- the staged check of a17 (window attention, RoPE, layer_scale). */
 int  ptts_decode_stages(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,
                         float* pcm, float* mimi_latent, float* transformer_out);
+/* Voice cloning, the part the reference holds natively: projectSpeakerConditioning
+ * (internal/onnx/voice_encode.go:119-158) -- Mimi-encoder latents [frames, 512] (host) times flow_lm.speaker_proj_weight
+ * [d_model, 512] -> voice embedding [frames, d_model] (host), which a request then carries as `voice_embedding`.  The Mimi encoder
+ * itself has no native reference (mimi.go:14,791-794: ErrMimiEncoderNotImplemented) and is not built.  PTTS_EFORMAT when the
+ * checkpoint has no speaker projection tensor. */
+int  ptts_speaker_project(ptts_model* m, const float* latent, int64_t frames, float* out);
 /* The device draw of FlowLM.makeGaussianNoise (flow_lm.go:386-408) for one request: out[rows, ldim] (host) receives exactly the
  * rows ptts_generate would consume for (noise_seed = seed, temperature) -- so that a test can hand the same noise to a reference. */
 int  ptts_noise_rows(ptts_model* m, uint64_t seed, float temperature, int32_t rows, float* out);
