@@ -400,6 +400,7 @@ struct Walker {
         }
         d.final_linear = step_linear(fn + "final_layer.linear", true);
         // speaker conditioning projection (onnx/voice_encode.go:160-202: either name; [VoiceEmbeddingDim, mimiEncoderLatentDim]), optional
+        d.speaker_proj = Lin{};   // (the fill pass starts from the planned Desc)
         for (const char* nm : {"flow_lm.speaker_proj_weight", "condition_provider.conditioners.speaker_wavs.output_proj.weight"}) {
             if (!has(nm) || d.speaker_proj.w != NONE) continue;
             expect_rank(nm, 2);

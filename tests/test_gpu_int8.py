@@ -25,7 +25,10 @@ def models(pkg, tmp_path_factory):
     cfg = dataclasses.replace(synth.SynthConfig.tiny(), speaker_proj=True)
     tens = synth.make_checkpoint(cfg, seed=1234)
     path = str(tmp_path_factory.mktemp("ckpt") / "tiny_sp.safetensors")
-    synth.write_safetensors(path, tens)
+    # a BF16 file: what PTTS_WEIGHTS_INT8 keeps in bf16 (everything the step does not stream: Mimi, time embedding) is then exact,
+    # like in the PTTS_WEIGHTS_BF16 tests, and the only thing that differs from the file is the int8 rounding under test
+    synth.write_safetensors(path, tens, dtype="BF16")
+    tens = synth.quantize_like_file(tens, "BF16")
     om_q = O.OracleModel(synth.dequantized_int8_checkpoint(tens))     # f32 math on the effective int8 weights
     om_f = O.OracleModel(tens)                                        # the unquantized model
     gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_INT8)
@@ -124,7 +127,7 @@ def test_speaker_projection_matches_the_reference_loop(pkg, models):
     # end to end: the projected embedding as voice conditioning (f32-weights model: the int8 one is covered above)
     gf = pkg.Model.open(gm_path(pkg, tens), device=0)
     emb = gf.speaker_project(lat[:9])
-    cfgv = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=3, want_latents=True, voice_embedding=pkg.VoiceEmbedding(emb))
+    cfgv = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=3, want_latents=True, voice_embedding=pkg.VoiceEmbedding(emb, (1,) + emb.shape))
     res = pkg.Runtime(gf).generate([1, 2, 3], cfgv)
     ref = om_f.generate([1, 2, 3], max_steps=3, eos_threshold=1e30, voice_emb=O.linear(lat[:9], w))
     parity("latents with a projected voice embedding", res.latents, ref["latents"], (2.5e-4, 5e-2))
