@@ -63,7 +63,11 @@ typedef struct ptts_opts {
                                 the GPU and there is no gap between steps; 1: the step is captured once into a hipGraph and
                                 replayed (one host call per step, ~8 us of idle GPU between replays: up to 3 % slower, but the
                                 launching thread needs a fraction of the CPU time) */
-    int32_t reserved[11];
+    int32_t step_plan;       /* launch plan of the AR step, for A/B measurement (results agree to rounding): 0 default: every activation
+                                edge in f32, LayerNorms in the consumers' prologues; 1: the flow net's mlp0 -> mlp2 edge as split bf16
+                                planes; 2: planes on every edge, norm1 / out_norm as their own launch, norm2 folded into linear1's
+                                epilogue.  1 and 2 measured no faster (DESIGN.md "What the measurements changed") */
+    int32_t reserved[10];
 } ptts_opts;
 
 void ptts_default_opts(ptts_opts* o);
