@@ -143,6 +143,9 @@ def spawn_ranks(n: int, argv: list) -> int:
     return rc
 
 
+NATIVE_BROADCAST = False   # --native-broadcast: the library's own ncclBroadcast (ptts_rccl_broadcast) instead of torch.distributed's
+
+
 def open_model(pkg, path, wl, rank, world, device):
     """Two-phase open: rank 0 fills the device arena, one RCCL broadcast hands it to the other ranks."""
     kw = dict(device=device, weights=wl["weights"], kv=wl["kv"], max_batch=wl["batch"], use_graph=True)   # configs[2]: hipGraph-captured step
@@ -155,7 +158,12 @@ def open_model(pkg, path, wl, rank, world, device):
     if rank == 0:
         model = pkg.Model.open_planned(plan, arena.data_ptr(), fill=True)
         torch.cuda.synchronize()
-    dist.broadcast(arena, src=0)          # the only collective of the whole job (weights, once)
+    if NATIVE_BROADCAST:                  # the same broadcast issued by libptts_hip.so itself (what a host without PyTorch calls)
+        ids = [pkg.runtime.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0, device=torch.device(f"cuda:{device}"))
+        pkg.runtime.rccl_broadcast(arena.data_ptr(), nbytes, rank, world, ids[0], device)
+    else:
+        dist.broadcast(arena, src=0)      # the only collective of the whole job (weights, once)
     torch.cuda.synchronize()
     if rank != 0:
         model = pkg.Model.open_planned(plan, arena.data_ptr(), fill=False)
@@ -409,6 +417,7 @@ def main():
                                                                   "stretch each other, and rocprofv3 slows launches that are issued one by one)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 counter passes that fill roofline.traffic")
     ap.add_argument("--cpu-frames", type=int, default=63)
+    ap.add_argument("--native-broadcast", action="store_true", help="N > 1: broadcast the weight arena with the library's own RCCL call (ptts_rccl_broadcast)")
     ap.add_argument("--startup-only", action="store_true", help="CPU rehearsal of the N-rank start-up (gloo): plan, fill, ONE broadcast, sharding; no GPU, no timing")
     args = ap.parse_args()
 
@@ -424,6 +433,8 @@ def main():
 
     if args.startup_only:
         return startup_only(rank, world)
+    global NATIVE_BROADCAST
+    NATIVE_BROADCAST = bool(args.native_broadcast)
 
     traffic = None
     if rank == 0 and world == 1 and not args.no_traffic:

@@ -125,6 +125,21 @@ int ptts_plan_fill_host(const ptts_plan* p, void* host_arena) {
 }
 void ptts_plan_free(ptts_plan* p) { delete p; }
 
+int ptts_rccl_unique_id(uint8_t out[128]) {
+    return guard([&] {
+        if (!out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        require_device();
+        rccl_unique_id(out);
+    });
+}
+
+int ptts_rccl_broadcast(void* device_buf, size_t bytes, int32_t rank, int32_t n_ranks, const uint8_t id[128], int32_t device) {
+    return guard([&] {
+        require_device();
+        rccl_broadcast(device_buf, bytes, rank, n_ranks, id, device);
+    });
+}
+
 int ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_model** out) {
     int rc = guard([&] {
         if (!p || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");

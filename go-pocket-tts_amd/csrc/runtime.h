@@ -211,6 +211,10 @@ size_t tokenizer_vocab(const Tokenizer& t);
 void tokenizer_free(Tokenizer* t);
 std::string nfkc_utf8(const std::string& s);
 
+// the weight broadcast of a multi-GPU start-up (broadcast.cpp)
+void rccl_unique_id(uint8_t out[128]);
+void rccl_broadcast(void* device_buf, size_t bytes, int rank, int n_ranks, const uint8_t id[128], int device);
+
 // request dispatcher (dispatcher.cpp)
 struct Dispatcher;
 typedef int (*ExecFn)(void* user, int worker, const ptts_request* reqs, int32_t n, ptts_result* results, char* err, int32_t errlen);

@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "ptts_model_share", "ptts_model_set_use_graph", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
     "ptts_tokenizer_open", "ptts_tokenizer_open_bytes", "ptts_tokenizer_free", "ptts_tokenizer_vocab_size", "ptts_tokenizer_encode",
-    "ptts_tokenizer_encode_cb", "ptts_text_nfkc",
+    "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast",
 ]
 
 
@@ -820,6 +820,20 @@ class Dispatcher:
 
 
 # ---- text front end (internal/text/prepare.go) ---------------------------------------------------------
+def rccl_unique_id() -> bytes:
+    """ncclGetUniqueId through the library (rank 0 of a multi-GPU start-up)."""
+    buf = (C.c_uint8 * 128)()
+    _check(lib().ptts_rccl_unique_id(buf))
+    return bytes(buf)
+
+
+def rccl_broadcast(device_ptr: int, nbytes: int, rank: int, n_ranks: int, unique_id: bytes, device: int = 0):
+    """The weight-arena broadcast (root = rank 0) over RCCL / xGMI, inside the library; every rank calls it."""
+    L = lib()
+    L.ptts_rccl_broadcast.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_char_p, C.c_int32]
+    _check(L.ptts_rccl_broadcast(C.c_void_p(device_ptr), nbytes, rank, n_ranks, unique_id, device))
+
+
 class Tokenizer:
     """tokenizer.Tokenizer (internal/tokenizer/tokenizer.go) backed by the library's SentencePiece unigram encoder
     (NewSentencePieceTokenizer / NewSentencePieceTokenizerFromBytes, sentencepiece.go:19-33)."""

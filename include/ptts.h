@@ -98,6 +98,12 @@ int    ptts_plan_create(const char* safetensors_path, const ptts_opts* opts, ptt
 int    ptts_plan_create_bytes(const void* data, size_t len, const ptts_opts* opts, ptts_plan** out);
 size_t ptts_plan_arena_bytes(const ptts_plan* p);
 int    ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_model** out); /* consumes p */
+/* The broadcast itself, for hosts that have no collective library of their own (the reference's Go server): rank 0 makes the id
+ * (ncclGetUniqueId), hands the 128 bytes to the other processes over the channel that started them, then EVERY rank calls
+ * ptts_rccl_broadcast on its arena (root = rank 0; one ncclCommInitRank + ncclBroadcast + ncclCommDestroy over RCCL / xGMI).
+ * librccl is loaded on first use (PTTS_RCCL_LIB overrides the name). */
+int    ptts_rccl_unique_id(uint8_t out[128]);
+int    ptts_rccl_broadcast(void* device_buf, size_t bytes, int32_t rank, int32_t n_ranks, const uint8_t id[128], int32_t device);
 /* host image of the arena (ptts_plan_arena_bytes() bytes), for hosts that upload / broadcast it themselves; needs no GPU */
 int    ptts_plan_fill_host(const ptts_plan* p, void* host_arena);
 void   ptts_plan_free(ptts_plan* p);

@@ -796,3 +796,25 @@ if len(sys.argv) > 1:
         assert "alive" in r.stdout, r.stderr[-2000:]
         assert r.returncode == want, (r.returncode, r.stderr[-2000:])
         assert "terminate called" not in r.stderr and "bad_variant_access" not in r.stderr, r.stderr[-2000:]
+
+
+def test_library_broadcast_single_rank_then_adopt(pkg, tiny):
+    """ptts_rccl_unique_id / ptts_rccl_broadcast (the weight broadcast a host without PyTorch issues): with one rank the arena must
+    come back untouched and open as a model; the N-rank path is the same three RCCL calls with nranks = N."""
+    import torch
+    _, path, om, gm = tiny
+    plan, nbytes = pkg.Model.plan(path)
+    arena = torch.empty(nbytes, dtype=torch.uint8, device="cuda:0")
+    m1 = pkg.Model.open_planned(plan, arena.data_ptr(), fill=True)
+    torch.cuda.synchronize()
+    before = arena.clone()
+    uid = pkg.runtime.rccl_unique_id()
+    assert len(uid) == 128 and any(uid)
+    pkg.runtime.rccl_broadcast(arena.data_ptr(), nbytes, 0, 1, uid, 0)
+    torch.cuda.synchronize()
+    assert torch.equal(arena, before)
+    cfg = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=2, want_latents=True)
+    a = pkg.Runtime(m1).generate([1, 2, 3], cfg)
+    b = pkg.Runtime(gm).generate([1, 2, 3], cfg)
+    assert np.array_equal(a.pcm, b.pcm)
+    m1.close()
