@@ -125,6 +125,17 @@ int ptts_plan_fill_host(const ptts_plan* p, void* host_arena) {
 }
 void ptts_plan_free(ptts_plan* p) { delete p; }
 
+int ptts_dsp_apply(float* samples, int64_t n, int32_t normalize, int32_t dc_block, double fade_in_ms, double fade_out_ms) {
+    return guard([&] {
+        if ((!samples && n > 0) || n < 0) throw Error(PTTS_EINVAL, "audio: nil samples");
+        const int sr = 24000;   // audio.ExpectedSampleRate
+        if (normalize) dsp_peak_normalize(samples, n);
+        if (dc_block) dsp_dc_block(samples, n, sr);
+        if (fade_in_ms > 0) dsp_fade_in(samples, n, sr, fade_in_ms);
+        if (fade_out_ms > 0) dsp_fade_out(samples, n, sr, fade_out_ms);
+    });
+}
+
 int ptts_rccl_unique_id(uint8_t out[128]) {
     return guard([&] {
         if (!out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");

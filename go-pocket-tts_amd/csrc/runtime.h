@@ -211,6 +211,12 @@ size_t tokenizer_vocab(const Tokenizer& t);
 void tokenizer_free(Tokenizer* t);
 std::string nfkc_utf8(const std::string& s);
 
+// optional post-processing of a finished utterance (dsp.cpp; internal/audio/dsp.go)
+void dsp_peak_normalize(float* s, int64_t n);
+void dsp_dc_block(float* s, int64_t n, int sample_rate);
+void dsp_fade_in(float* s, int64_t n, int sample_rate, double ms);
+void dsp_fade_out(float* s, int64_t n, int sample_rate, double ms);
+
 // the weight broadcast of a multi-GPU start-up (broadcast.cpp)
 void rccl_unique_id(uint8_t out[128]);
 void rccl_broadcast(void* device_buf, size_t bytes, int rank, int n_ranks, const uint8_t id[128], int device);

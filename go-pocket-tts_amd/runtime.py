@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "ptts_model_share", "ptts_model_set_use_graph", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
     "ptts_tokenizer_open", "ptts_tokenizer_open_bytes", "ptts_tokenizer_free", "ptts_tokenizer_vocab_size", "ptts_tokenizer_encode",
-    "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast",
+    "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast", "ptts_dsp_apply",
 ]
 
 
@@ -820,6 +820,15 @@ class Dispatcher:
 
 
 # ---- text front end (internal/text/prepare.go) ---------------------------------------------------------
+def dsp_apply(samples, normalize: bool = False, dc_block: bool = False, fade_in_ms: float = 0.0, fade_out_ms: float = 0.0) -> np.ndarray:
+    """audio.PeakNormalize / DCBlock / FadeIn / FadeOut in the CLI's order (dsp.go:12-78, synth.go:361-390); returns a new array."""
+    out = np.array(samples, dtype=np.float32, copy=True).reshape(-1)
+    L = lib()
+    L.ptts_dsp_apply.argtypes = [_FP, C.c_int64, C.c_int32, C.c_int32, C.c_double, C.c_double]
+    _check(L.ptts_dsp_apply(_fp(out), out.size, 1 if normalize else 0, 1 if dc_block else 0, float(fade_in_ms), float(fade_out_ms)))
+    return out
+
+
 def rccl_unique_id() -> bytes:
     """ncclGetUniqueId through the library (rank 0 of a multi-GPU start-up)."""
     buf = (C.c_uint8 * 128)()

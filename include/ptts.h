@@ -181,6 +181,12 @@ void ptts_free_result(ptts_result* r);
  * 24 kHz, mono, 16 bit, RIFF and data sizes 0xFFFFFFFF. */
 void ptts_wav_header_streaming(uint8_t out[44]);
 
+/* Optional post-processing of a finished utterance, in place, in the order the CLI applies it (cmd/pockettts/synth.go:361-390):
+ * PeakNormalize, DCBlock (20 Hz high-pass), FadeIn, FadeOut (internal/audio/dsp.go:12-78); 24 kHz.  Host samples, host code.
+ * Normalise and the fades are bit-exact restatements; the DC block's biquad comes from a third-party module in the reference and
+ * is held to the properties the reference's tests state (parity unpinned). */
+int  ptts_dsp_apply(float* samples, int64_t n, int32_t normalize, int32_t dc_block, double fade_in_ms, double fade_out_ms);
+
 /* ---- Text front end (internal/text/prepare.go, chunk.go) -------------------------------------------------
  * What Synthesize does before it calls the runtime: normalise the text, cut it into sentence-based chunks of <= max_tokens
  * tokens, and derive each chunk's step budget and EOS tail.  The SentencePiece encoder is the caller's. */
