@@ -1365,8 +1365,13 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     // of latency-bound launches that leaves most of the chip idle, the decoder is throughput work, and every decoder op is
     // causal, so frames [f0, f1) can be decoded as soon as step f1-1 has finished.
     const int64_t spf = d.samples_per_frame;
-    const int T = ms_max;
-    if ((int64_t)T * d.up_stride > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)T * d.up_stride));
+    // The decoder's RoPE table ends at ROPE_SEQ positions (mimi.go:498): like the reference, a step budget beyond that is not an
+    // error by itself -- generating that many frames is (the decoder is sized for what can be decoded).
+    const int t_limit = ROPE_SEQ / d.up_stride;
+    const int T = std::min(ms_max, t_limit);
+    auto too_long = [&](int frames) {
+        return Error(PTTS_EINVAL, strfmt("generate: mimi_decode: ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)frames * d.up_stride));
+    };
     MimiWs mw;
     mimi_setup(m, mw, B, T);
     mimi_zero_history(m, mw, m.stream2);   // nine small launches: under the AR loop instead of between the loop and the decoder
@@ -1425,6 +1430,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     bool* rows_used = nullptr;
     auto decode_upto = [&](int f1) {
         if (f1 <= f_done) return;
+        if (f1 > T) throw too_long(f1);
         hipEvent_t e = next_event();
         PTTS_HIP(hipEventRecord(e, s));
         PTTS_HIP(hipStreamWaitEvent(m.stream2, e, 0));

@@ -818,3 +818,24 @@ def test_library_broadcast_single_rank_then_adopt(pkg, tiny):
     b = pkg.Runtime(gm).generate([1, 2, 3], cfg)
     assert np.array_equal(a.pcm, b.pcm)
     m1.close()
+
+
+def test_step_budget_beyond_the_decoder_table_fails_only_if_that_many_frames_are_generated(pkg, tiny):
+    """The Mimi RoPE table has 8192 positions = 512 frames (mimi.go:498).  The reference accepts any MaxSteps and fails in
+    mimi_decode only when more frames than that were actually produced; so does the library: a 600-step budget with an early EOS
+    synthesises, the same budget without an EOS is refused with the reference's decode error."""
+    _, _, om, gm = tiny
+    toks = [10, 20, 30]
+    probe = om.generate(toks, max_steps=12, eos_threshold=1e30, frames_after_eos=2)
+    lg = probe["eos_logits"]
+    s_eos = int(np.argmax(lg[1:8])) + 1
+    while s_eos > 0 and lg[:s_eos].max() >= lg[s_eos]:   # must be the first logit above the threshold
+        s_eos -= 1
+    thr = float((lg[s_eos] + (lg[:s_eos].max() if s_eos else lg[s_eos] - 1.0)) / 2)
+    ref = om.generate(toks, max_steps=600, eos_threshold=thr, frames_after_eos=2)
+    got = pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=thr, max_steps=600, frames_after_eos=2, want_latents=True))
+    assert (got.eos_step, got.n_frames) == (ref["eos_step"], ref["n_frames"]) and got.n_frames < 20
+    parity("latents (600-step budget, early EOS)", got.latents, ref["latents"], MULTI_LAT_TOL)
+    with pytest.raises(pkg.PttsError) as e:
+        pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=600))
+    assert "rope cos/sin sequence length too small" in str(e.value) and "mimi_decode" in str(e.value)
