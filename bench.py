@@ -256,7 +256,7 @@ def roofline_pass(pkg, model, wl, prompts, voice, traffic=None):
 # (KiB) reports half of the bytes of wide coalesced reads on gfx950 -> doubled; WRITE_SIZE (KiB) is exact for 16-byte stores.
 # ------------------------------------------------------------------------------------------------------------------
 def _pmc_pass(counters, out_dir, steps):
-    exe = shutil.which("rocprofv3")
+    exe = shutil.which("rocprofv3") or next((p for p in ("/opt/rocm/bin/rocprofv3",) if os.path.exists(p)), None)
     if not exe:
         return None, "rocprofv3 not found"
     env = dict(os.environ, PTTS_PROBE_STEPS=str(steps), TMPDIR=tempfile.gettempdir())
