@@ -854,10 +854,11 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         g.R = dR.as<float>(); g.epi = epi;
         g.M = M; g.N = N; g.K = K;
         if (!gemm2_supported(g) || !gemm3_supported(g)) throw Error(PTTS_EINVAL, "shape not supported");
-        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies)
+        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies), 50: k_gemm4 (persistent form), 51: k_gemm4 (two-stage form)
         auto run = [&](int v, float* c) {
             GemmArgs h = g; h.C = c;
             if (v == 40) launch_gemm(h, nullptr);
+            else if (v == 50 || v == 51) { if (!gemm4_supported(h)) throw Error(PTTS_EINVAL, "shape not supported by k_gemm4"); g_gemm4_cfg = v - 50; launch_gemm4(h, nullptr); g_gemm4_cfg = 0; }
             else if (v >= 3) { g_gemm3_cfg = v >= 30 ? v - 30 : 0; launch_gemm3(h, nullptr); g_gemm3_cfg = 0; }
             else launch_gemm2(h, nullptr);
         };
@@ -883,6 +884,33 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
             for (size_t i = 0; i < nc; i++) { float d = std::fabs(c1[i] - c2[i]); if (!(d <= md)) md = d; }
             *maxdiff = md;
         }
+    });
+}
+
+int ptts_debug_gemm4_stamps(int32_t M, int32_t N, int32_t K, uint64_t* out /* [2][64][8][8] */) {
+    return guard([&] {
+        require_device();
+        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N, ns = 2 * 64 * 8 * 8;
+        std::vector<float> ha(na);
+        std::vector<uint16_t> hw(nw);
+        uint32_t st = 12345u;
+        auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((float)(st >> 8) / 8388608.0f) - 1.0f; };
+        for (auto& x : ha) x = rnd();
+        for (auto& x : hw) { float f = rnd() * 0.05f; uint32_t u; memcpy(&u, &f, 4); x = (uint16_t)(u >> 16); }
+        Tmp dA(na * 4), dW(nw * 2), dC(nc * 4), dS(ns * 8);
+        up(dA.p, ha.data(), na * 4); up(dW.p, hw.data(), nw * 2);
+        PTTS_HIP(hipMemset(dS.p, 0, ns * 8));
+        GemmArgs g;
+        g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
+        g.W = dW.p; g.w_bf16 = 1; g.ldw = K;
+        g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
+        g.M = M; g.N = N; g.K = K;
+        if (!gemm4_supported(g)) throw Error(PTTS_EINVAL, "shape not supported by k_gemm4");
+        for (int i = 0; i < 3; i++) launch_gemm4(g, nullptr);
+        g.dbg = dS.as<unsigned long long>();
+        launch_gemm4(g, nullptr);
+        PTTS_HIP(hipDeviceSynchronize());
+        down(out, dS.p, ns * 8);
     });
 }
 

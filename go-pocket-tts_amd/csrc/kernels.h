@@ -70,6 +70,7 @@ struct GemmArgs {
     const float* wg = nullptr; const float* wb = nullptr; float ln_eps = 1e-5f;
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
+    unsigned long long* dbg = nullptr;   // k_gemm4 stamps (tools/stamps_gemm4.py only; null in the product)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t stream);   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
 bool gemm_wres_supported(const GemmArgs& a);   // gemm_wres.hip: K, N <= 256 with the whole weight matrix resident in LDS
@@ -79,6 +80,9 @@ void launch_gemm2(const GemmArgs& a, hipStream_t stream);
 bool gemm3_supported(const GemmArgs& a);   // direct-to-register activations, 256-row blocks (gemm3.hip)
 void launch_gemm3(const GemmArgs& a, hipStream_t stream);
 extern thread_local int g_gemm3_cfg;
+bool gemm4_supported(const GemmArgs& a);   // both operands through LDS by LDS-DMA, 128-row x 256-column blocks (gemm4.hip): K >= 256, N % 256 == 0, bf16 weights
+void launch_gemm4(const GemmArgs& a, hipStream_t stream);
+extern thread_local int g_gemm4_cfg;
 
 // Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.

@@ -150,6 +150,8 @@ void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 64 && a.Wt && skinny_supported(a, 1)) { launch_skinny(a, SkinnyFuse{}, 1, nullptr, stream); return; }
     static const int wres = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 1; }();   // A/B measurement
     if (wres && force != 2 && gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
+    static const int g4 = [] { const char* e = getenv("PTTS_GEMM4"); return e ? atoi(e) : 0; }();   // A/B measurement: 1 persistent, 2 two-stage
+    if (g4 && force != 2 && gemm4_supported(a)) { g_gemm4_cfg = g4 == 2 ? 1 : 0; launch_gemm4(a, stream); g_gemm4_cfg = 0; return; }
     if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     note_launch("k_gemm");

@@ -336,6 +336,8 @@ int ptts_debug_step_stamps(ptts_batch* b, int32_t lsd_steps, uint64_t* out /* [c
                            int32_t cap_desc, int32_t* n_desc);
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
+/* clock stamps of block 0 of the persistent k_gemm4 over its first two tiles (tools/stamps_gemm4.py) */
+int ptts_debug_gemm4_stamps(int32_t M, int32_t N, int32_t K, uint64_t* out /* [2 tiles][64 steps][8 waves][8 stamps] */);
 
 /* audio.WritePCM16Samples on the device (internal/audio/wav_stream.go:43-54), without the byte packing */
 int ptts_op_pcm16(const float* samples, int64_t n, int16_t* out);
