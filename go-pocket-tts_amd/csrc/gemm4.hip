@@ -308,8 +308,9 @@ __global__ __launch_bounds__(G4P_NW * 64, 2) void k_gemm4p(GemmArgs a) {
         for (int s = 0; s < nsteps; s++) {
             // this step's pieces have landed once all but the six youngest DMAs (the following step's) are done
             G4_STAMP(0, s); G4_STAMP(7, s);
-            if (s + 1 < nsteps || has_next) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (lgkmcnt(0): every LDS read of the previous step has returned before this wave lets the others refill that stage)
+            if (s + 1 < nsteps || has_next) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             G4_STAMP(1, s);
             __builtin_amdgcn_s_barrier();   // ... everyone's have, and everyone has finished reading the stage refilled next
             asm volatile("" ::: "memory");
@@ -407,8 +408,9 @@ void launch_gemm4(const GemmArgs& a, hipStream_t stream) {
     }
     const int ncol = a.N / G4_BN, npan = (a.M + G4_BM - 1) / G4_BM;
     dim3 grid((unsigned)(((npan + 7) / 8) * 8 * ncol));
-    if (a.aop == AOP_ELU) hipLaunchKernelGGL(k_gemm4<true>, grid, dim3(G4_NW * 64), 0, stream, a);
-    else hipLaunchKernelGGL(k_gemm4<false>, grid, dim3(G4_NW * 64), 0, stream, a);
+    static const int pad = [] { const char* e = getenv("PTTS_G4_PAD"); return e ? atoi(e) : 0; }();   // diagnosis: extra LDS per block (40000: one block per CU)
+    if (a.aop == AOP_ELU) hipLaunchKernelGGL(k_gemm4<true>, grid, dim3(G4_NW * 64), pad, stream, a);
+    else hipLaunchKernelGGL(k_gemm4<false>, grid, dim3(G4_NW * 64), pad, stream, a);
 }
 
 }  // namespace ptts

@@ -72,7 +72,8 @@ struct GemmArgs {
     int aop = AOP_NONE, epi = EPI_NONE;
     unsigned long long* dbg = nullptr;   // k_gemm4 stamps (tools/stamps_gemm4.py only; null in the product)
 };
-void launch_gemm(const GemmArgs& a, hipStream_t stream);   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
+void launch_gemm(const GemmArgs& a, hipStream_t stream);
+bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream);   // a product with the RoPE epilogue (GemmArgs::rope_cos): k_gemm4 or k_gemm3; false: no kernel takes it (the caller rotates in a second launch)   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
 bool gemm_wres_supported(const GemmArgs& a);   // gemm_wres.hip: K, N <= 256 with the whole weight matrix resident in LDS
 void launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 bool gemm2_supported(const GemmArgs& a);

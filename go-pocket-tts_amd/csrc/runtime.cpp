@@ -414,8 +414,7 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
             GemmArgs gq = mk(m, pxn, flat(D), L.in_proj, pqkv, flat(3 * D), R);
             gq.rope_cos = m.at<float>(d.rope_cos); gq.rope_sin = m.at<float>(d.rope_sin);   // q and k are rotated in the epilogue
             gq.rope_cols = 2 * D; gq.rope_hd = d.hd; gq.rope_row_pos = d_pos;
-            if (gemm3_supported(gq)) launch_gemm3(gq, s);
-            else {
+            if (!launch_gemm_rope(gq, s)) {
                 gq.rope_cos = gq.rope_sin = nullptr; gq.rope_row_pos = nullptr;
                 launch_gemm(gq, s);
                 launch_rope_rows(pqkv, flat(3 * D), 0, d.heads, d.hd, d_pos, 0, 0, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
@@ -979,8 +978,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
             GemmArgs gq = mk(m, n1, flat(C), L.in_proj, qkvx, qm, R);
             gq.rope_cos = m.at<float>(d.rope_cos); gq.rope_sin = m.at<float>(d.rope_sin);   // q and k are rotated in the epilogue
             gq.rope_cols = 2 * C; gq.rope_hd = d.mimi_hd; gq.rope_pos0 = t0; gq.rope_rows_per_seg = CT;
-            if (gemm3_supported(gq)) launch_gemm3(gq, s);
-            else {
+            if (!launch_gemm_rope(gq, s)) {
                 gq.rope_cos = gq.rope_sin = nullptr;
                 launch_gemm(gq, s);
                 launch_rope_rows(qkvx, qm, 0, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);

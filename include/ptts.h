@@ -336,6 +336,9 @@ int ptts_debug_step_stamps(ptts_batch* b, int32_t lsd_steps, uint64_t* out /* [c
                            int32_t cap_desc, int32_t* n_desc);
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
+/* the same product `reps` times on an operand re-copied on the device before every launch: runs whose bits differ from the first (a race check) */
+int ptts_debug_gemm_repeat(int32_t M, int32_t N, int32_t K, int32_t variant, int32_t epi, int32_t reps, int32_t mode /* 1: RoPE epilogue, 2: segmented output rows */,
+                           int32_t* bad_runs, float* maxdiff);
 /* clock stamps of block 0 of the persistent k_gemm4 over its first two tiles (tools/stamps_gemm4.py) */
 int ptts_debug_gemm4_stamps(int32_t M, int32_t N, int32_t K, uint64_t* out /* [2 tiles][64 steps][8 waves][8 stamps] */);
 

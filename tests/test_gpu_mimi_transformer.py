@@ -129,3 +129,21 @@ def test_window_kernel_random_against_the_oracle(pkg, t, ctx):
     assert pkg.runtime.last_attention_kernel() == "k_attn_window"
     want = O.attention_positions(q, k, v, pos, pos, ctx)
     parity(f"k_attn_window T={t} ctx={ctx}", out, want, (1e-4, None), scale_abs=False)   # ops/tolerance.go:13-24 kernel level
+
+
+def test_wide_batch_is_bit_reproducible_and_slot_symmetric(pkg, mimi_full):
+    """32 utterances x 64 frames (32768 rows: the many-row kernels with several blocks per CU and several tiles per block), the
+    same latents in slots i and 31 - i, decoded three times: the transformer output of slot i equals that of slot 31 - i and that
+    of every other run BIT FOR BIT.  No kernel of the decoder may depend on where a row sits or on timing; a data race in a
+    staging pipeline shows up here first (an LDS-DMA GEMM that passed every parity test did not pass this one and does not ship:
+    DESIGN.md, round 2)."""
+    dtype, om, gm = mimi_full
+    rng = np.random.default_rng(5)
+    half = lat(rng, 16, 64)
+    x = np.concatenate([half, half[::-1]], 0)
+    runs = [gm.decode_stages(x) for _ in range(3)]
+    for r, (pcm, ml, xf) in enumerate(runs):
+        for i in range(16):
+            assert np.array_equal(xf[i], xf[31 - i]), (dtype, r, i)
+            assert np.array_equal(pcm[i], pcm[31 - i]), (dtype, r, i)
+        assert np.array_equal(xf, runs[0][2]) and np.array_equal(pcm, runs[0][0]), (dtype, r)
