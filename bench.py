@@ -566,6 +566,22 @@ def main():
                 log(f"[bench] b1 roofline pass failed: {e}")
             v1.close()
             m1.close()
+        if not args.no_b1 and args.workload == "b64_10s_bf16":
+            # N4 (BASELINE.json configs[4] names int8): the headline workload on per-row-scaled int8 step weights (PTTS_WEIGHTS_INT8;
+            # half the bytes of the bf16 step), bf16 KV -- what halving the weight bytes buys a launch-latency-bound step
+            try:
+                wl8 = dict(WORKLOADS["b64_10s_bf16"], weights=pkg.runtime.WEIGHTS_INT8)
+                m8, _ = open_model(pkg, path, wl8, 0, 1, local)
+                v8 = m8.upload_voice(pkg.VoiceModelState(voice_modules(pkg, cfg)))
+                n8 = max(3, args.steps // 2)
+                e8, _, _ = run_workload(pkg, m8, wl8, prompts, v8, n8, 1, lambda: None, sync)
+                result["int8_weights"] = {"value": round(wl8["batch"] * wl8["frames"] * FRAME_SEC * n8 / e8, 1), "unit": "x real-time",
+                                          "ms_per_step": round(1e3 * e8 / n8, 3), "arena_mb": round(m8.info.arena_bytes / 1e6, 1),
+                                          "config": "same workload, weights = PTTS_WEIGHTS_INT8 (weight-only, per-row scales, converted to bf16 in registers), bf16 KV"}
+                v8.close()
+                m8.close()
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] int8 pass failed: {e}")
         if not args.no_cpu_baseline:
             try:
                 p32 = checkpoint_path(pkg, "F32", 0, lambda: None)
