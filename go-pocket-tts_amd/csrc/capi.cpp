@@ -921,13 +921,8 @@ int ptts_debug_gemm_repeat(int32_t M, int32_t N, int32_t K, int32_t variant, int
         if (mode & 2) { g.C = dCseg.as<float>(); g.cmap = RowMap{N, rps, (int64_t)seg_stride}; g.R = nullptr; if (g.epi >= EPI_RESADD) g.epi = EPI_NONE; }
         if (!gemm3_supported(g) || (variant >= 50 && !gemm4_supported(g))) throw Error(PTTS_EINVAL, "shape not supported");
         std::vector<float> first(nc), cur(nc), ref, ref_nr;
-        if (getenv("PTTS_G4_VERBOSE") && (mode & 1) && !(mode & 2)) {   // trusted values from k_gemm3: with the rotation and without it
-            PTTS_HIP(hipMemcpy(dA2.p, dA.p, na * 4, hipMemcpyDeviceToDevice));
-            ref.resize(nc); ref_nr.resize(nc);
-            launch_gemm3(g, nullptr); PTTS_HIP(hipDeviceSynchronize()); down(ref.data(), dC.p, nc * 4);
-            GemmArgs h = g; h.rope_cos = h.rope_sin = nullptr;
-            launch_gemm3(h, nullptr); PTTS_HIP(hipDeviceSynchronize()); down(ref_nr.data(), dC.p, nc * 4);
-        }
+        std::vector<std::vector<float>> kept;   // PTTS_G4_VERBOSE: every run's output, compared with k_gemm3's AFTER the loop (launches before it changed the outcome)
+        const bool verbose_ref = getenv("PTTS_G4_VERBOSE") && (mode & 1) && !(mode & 2);
         *bad_runs = 0; *maxdiff = 0.f;
         for (int r = 0; r < reps; r++) {
             // the operand is rewritten by a device copy right before every launch: the product reads rows another kernel has just stored
@@ -939,6 +934,7 @@ int ptts_debug_gemm_repeat(int32_t M, int32_t N, int32_t K, int32_t variant, int
             float* host = r ? cur.data() : first.data();
             if (mode & 2) { for (size_t b0 = 0; b0 * rps < (size_t)M; b0++) { const size_t rows = std::min((size_t)rps, (size_t)M - b0 * rps); down(host + b0 * rps * N, dCseg.as<float>() + b0 * seg_stride, rows * N * 4); } }
             else down(host, dC.p, nc * 4);
+            if (verbose_ref) kept.push_back(r ? cur : first);
             if (r) {
                 float md = 0;
                 for (size_t i = 0; i < nc; i++) { float d = std::fabs(cur[i] - first[i]); if (!(d <= md)) md = d; }
@@ -975,6 +971,32 @@ int ptts_debug_gemm_repeat(int32_t M, int32_t N, int32_t K, int32_t variant, int
                         fprintf(stderr, "\n");
                     }
                 }
+            }
+        }
+        if (verbose_ref) {   // which run is wrong, and what the wrong element equals
+            PTTS_HIP(hipMemcpy(dA2.p, dA.p, na * 4, hipMemcpyDeviceToDevice));
+            ref.resize(nc); ref_nr.resize(nc);
+            launch_gemm3(g, nullptr); PTTS_HIP(hipDeviceSynchronize()); down(ref.data(), dC.p, nc * 4);
+            GemmArgs h = g; h.rope_cos = h.rope_sin = nullptr;
+            launch_gemm3(h, nullptr); PTTS_HIP(hipDeviceSynchronize()); down(ref_nr.data(), dC.p, nc * 4);
+            for (size_t r = 0; r < kept.size(); r++) {
+                int shown = 0; size_t nbad = 0;
+                for (size_t i = 0; i < nc; i++) if (kept[r][i] != ref[i]) {
+                    nbad++;
+                    if (shown++ < 4) {
+                        const int row = (int)(i / N), col = (int)(i % N);
+                        const size_t b4 = i - (col & 3);
+                        const int pos = row % rps, j = (col % 64) >> 1;
+                        fprintf(stderr, "  run %zu vs k_gemm3: C[%d][%d] = %.6f want %.6f | unrotated x0..x3 = %.6f %.6f %.6f %.6f | want four = %.6f %.6f %.6f %.6f | got four = %.6f %.6f %.6f %.6f | cos (%.6f %.6f) sin (%.6f %.6f)\n",
+                                r, row, col, kept[r][i], ref[i], ref_nr[b4], ref_nr[b4 + 1], ref_nr[b4 + 2], ref_nr[b4 + 3], ref[b4], ref[b4 + 1], ref[b4 + 2], ref[b4 + 3],
+                                kept[r][b4], kept[r][b4 + 1], kept[r][b4 + 2], kept[r][b4 + 3], hcs[(size_t)pos * 32 + (j & ~1)], hcs[(size_t)pos * 32 + (j | 1)], hsn[(size_t)pos * 32 + (j & ~1)], hsn[(size_t)pos * 32 + (j | 1)]);
+                        // neighbours: the same lane's previous / next column tile and row tile
+                        if (col >= 16 && col + 16 < N && row >= 16)
+                            fprintf(stderr, "      same row, column - 16: want %.6f got %.6f unrot %.6f; column + 16: want %.6f unrot %.6f; row - 16 same column: want %.6f unrot %.6f\n",
+                                    ref[i - 16], kept[r][i - 16], ref_nr[i - 16], ref[i + 16], ref_nr[i + 16], ref[i - (size_t)16 * N], ref_nr[i - (size_t)16 * N]);
+                    }
+                }
+                fprintf(stderr, "  run %zu: %zu elements differ from k_gemm3\n", r, nbad);
             }
         }
     });
