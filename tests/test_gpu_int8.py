@@ -155,3 +155,80 @@ def test_speaker_projection_without_the_tensor_is_an_error(pkg, tmp_path):
         gm.speaker_project(np.zeros((2, 512), np.float32))
     assert "speaker_proj_weight" in str(e.value)
     gm.close()
+
+
+LONG_TEXT = ("Call me Ishmael. Some years ago, never mind how long precisely, having little or no money in my purse, and nothing particular "
+             "to interest me on shore, I thought I would sail about a little and see the watery part of the world. It is a way I have of "
+             "driving off the spleen and regulating the circulation. Whenever I find myself growing grim about the mouth; whenever it is a "
+             "damp, drizzly November in my soul; then, I account it high time to get to sea as soon as I can. This is my substitute for "
+             "pistol and ball. With a philosophical flourish Cato throws himself upon his sword; I quietly take to the ship.")
+
+
+def toy_encode(n_bins):
+    """A deterministic stand-in for the SentencePiece encoder (the tokenizer has its own tests): one id per letter or digit."""
+    return lambda s: [2 + (ord(ch) * 7) % (n_bins - 3) for ch in s if ch.isalnum()]
+
+
+def test_config4_long_form_with_a_cloned_voice_on_int8_weights(pkg, models):
+    """BASELINE.json configs[4] in miniature (the Mimi ENCODER is not built: its latents are an input here): a long text cut into
+    chunks by PrepareChunks, every chunk generated on the int8 weights under the voice embedding that the speaker projection makes
+    of encoder latents, chunks concatenated (service.go:107-153) -- against the same pipeline on the oracle (f32 math on the
+    effective int8 weights, the reference's projection loop), chunk by chunk."""
+    from oracle import text_prepare as TP
+    cfg, tens, om_q, _, gm = models
+    enc = toy_encode(cfg.n_bins)
+    rng = np.random.default_rng(4)
+    lat = rng.standard_normal((11, 512)).astype(np.float32)            # what a Mimi encoder would hand over: [frames, 512]
+    emb = gm.speaker_project(lat)
+    want_emb = O.linear(lat, tens["flow_lm.speaker_proj_weight"])
+    parity("cloned-voice embedding", emb, want_emb, (2e-4, 5e-3))
+    svc = pkg.Service(gm, enc, pkg.TTSConfig(eos_threshold=float("inf"), max_steps=3))
+    pairs = svc.synthesize_chunks(LONG_TEXT, voice_embedding=pkg.VoiceEmbedding(emb, (1,) + emb.shape))
+    want_chunks = TP.prepare_chunks(LONG_TEXT, enc, 50)
+    assert len(pairs) == len(want_chunks) >= 5
+    want = []
+    for (c, r), w in zip(pairs, want_chunks):
+        assert c.token_ids == w["token_ids"] and r.n_frames == 3
+        ref = om_q.generate(w["token_ids"], max_steps=3, eos_threshold=1e30, frames_after_eos=c.frames_after_eos, voice_emb=want_emb)
+        parity(f"configs[4] chunk pcm ({len(w['token_ids'])} tokens)", r.pcm, ref["pcm"], (3e-4, 1e-1))
+        want.append(ref["pcm"])
+    got = svc.synthesize(LONG_TEXT, voice_embedding=pkg.VoiceEmbedding(emb, (1,) + emb.shape))
+    parity("configs[4] long form, int8 + cloned voice", got, np.concatenate(want), (3e-4, 1e-1))
+
+
+def test_config4_shape_at_full_size(pkg, tmp_path):
+    """The same request shape on the reference's tensor shapes (b6369a24: 6 x 1024 transformer, full Mimi): 60 s of audio as four
+    15-second chunks (188 frames each) of one text in ONE batched call, int8 step weights, bf16 KV, graph replay, a 125-frame
+    cloned-voice embedding.  No oracle at this size in seconds: the properties -- every chunk runs its 188 frames and returns
+    188 * 1920 finite samples, two slots holding the same chunk return the same bits, graph replay equals plain launches, and the
+    first three frames of a chunk match the oracle on the effective int8 weights."""
+    synth = pkg.synth
+    cfg = dataclasses.replace(synth.SynthConfig.full(), speaker_proj=True)
+    tens = synth.make_checkpoint(cfg, seed=77)
+    path = str(tmp_path / "full_sp.safetensors")
+    synth.write_safetensors(path, tens, dtype="BF16")
+    gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_INT8, kv=1, max_batch=8, use_graph=True)
+    rng = np.random.default_rng(8)
+    lat = (rng.standard_normal((125, 512)) * 0.3).astype(np.float32)
+    emb = gm.speaker_project(lat)
+    voice = pkg.VoiceEmbedding(emb, (1,) + emb.shape)
+    prompts = synth.make_prompts(4, 40, cfg.n_bins, seed=3)
+    toks = [p.tolist() for p in prompts] + [prompts[1].tolist()]         # slot 4 repeats chunk 1
+    c = pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=188, voice_embedding=voice, want_latents=True)
+    out = gm.generate_batch(toks, [c] * 5)
+    assert all(o.n_frames == 188 and o.pcm.shape == (188 * 1920,) and np.isfinite(o.pcm).all() for o in out)
+    assert sum(o.pcm.size for o in out[:4]) == 4 * 188 * 1920   # 60.16 s at 24 kHz
+    assert np.array_equal(out[1].latents, out[4].latents) and np.array_equal(out[1].pcm, out[4].pcm)
+    gm.set_use_graph(False)
+    plain = gm.generate_batch(toks, [c] * 5)
+    assert all(np.array_equal(a.latents, b.latents) and np.array_equal(a.pcm, b.pcm) for a, b in zip(out, plain))
+    # head of chunk 0 against the oracle on the effective weights (three full-size frames take the oracle a few seconds)
+    q = synth.dequantized_int8_checkpoint(synth.quantize_like_file(tens, "BF16"))
+    om_q = O.OracleModel(q)
+    want_emb = O.linear(lat, q["flow_lm.speaker_proj_weight"])
+    parity("configs[4] full size: cloned-voice embedding", emb, want_emb, (2e-4, 5e-3))
+    ref = om_q.generate(toks[0], max_steps=3, eos_threshold=1e30, frames_after_eos=3, voice_emb=want_emb)
+    # free-running over three steps with a bf16 KV cache: observed 1.5e-3 of scale; the relative figure on the elements >= 10 % of the largest
+    parity("configs[4] full size: first three latent frames vs oracle(W^)", out[0].latents[:3], ref["latents"], (4e-3, 5e-2), rel_floor=1e-1)
+    om_q.close()
+    gm.close()
