@@ -70,10 +70,7 @@ __global__ __launch_bounds__(256) void k_attn_step(const int32_t* p_seg_len, con
     char* vbase = (char*)a.v + ((int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride) * ES;
     float* outp = a.out + (int64_t)seg * a.out_ld + h * 64;
     if (!live) {   // uniform per block
-        if (tid < 64) {
-            if (a.out_h) { a.out_h[(int64_t)seg * a.out_ld + h * 64 + tid] = 0; a.out_l[(int64_t)seg * a.out_ld + h * 64 + tid] = 0; }
-            else outp[tid] = 0.0f;
-        }
+        if (tid < 64) outp[tid] = 0.0f;
         return;
     }
     const int64_t pre_off = ((int64_t)a.layer * a.heads + h) * pre * 64 * ES;
@@ -213,11 +210,7 @@ __global__ __launch_bounds__(256) void k_attn_step(const int32_t* p_seg_len, con
 #pragma unroll
         for (int r = 0; r < 16; r++) { den += red_l[r]; num += red_o[r][tid]; }
         const float o = num / den;
-        if (a.out_h) {   // x = hi + lo to ~2^-17: split once here instead of in every column block of the out_proj launch
-            const unsigned short hi = f32_to_bf16_bits(o);
-            a.out_h[(int64_t)seg * a.out_ld + h * 64 + tid] = hi;
-            a.out_l[(int64_t)seg * a.out_ld + h * 64 + tid] = f32_to_bf16_bits(o - bf16_bits_to_f32(hi));
-        } else outp[tid] = o;
+        outp[tid] = o;
     }
 }
 

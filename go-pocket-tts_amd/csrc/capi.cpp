@@ -855,11 +855,10 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         g.R = dR.as<float>(); g.epi = epi;
         g.M = M; g.N = N; g.K = K;
         if (!gemm2_supported(g) || !gemm3_supported(g)) throw Error(PTTS_EINVAL, "shape not supported");
-        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies), 50: k_gemm4 (persistent form), 51: k_gemm4 (two-stage form)
+        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies)
         auto run = [&](int v, float* c) {
             GemmArgs h = g; h.C = c;
             if (v == 40) launch_gemm(h, nullptr);
-            else if (v == 50 || v == 51) { if (!gemm4_supported(h)) throw Error(PTTS_EINVAL, "shape not supported by k_gemm4"); g_gemm4_cfg = v - 50; launch_gemm4(h, nullptr); g_gemm4_cfg = 0; }
             else if (v >= 3) { g_gemm3_cfg = v >= 30 ? v - 30 : 0; launch_gemm3(h, nullptr); g_gemm3_cfg = 0; }
             else launch_gemm2(h, nullptr);
         };
@@ -877,7 +876,7 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *maxdiff = -1.0f;
         if (nc <= ((size_t)64 << 20)) {
-            run(variant >= 40 ? 3 : (variant >= 3 ? 2 : 3), dC2.as<float>());   // the dispatcher's choice and k_gemm4 are held against k_gemm3 (same k order: equal bits)
+            run(variant >= 40 ? 3 : (variant >= 3 ? 2 : 3), dC2.as<float>());   // the dispatcher's choice is held against k_gemm3 (same k order: equal bits)
             PTTS_HIP(hipDeviceSynchronize());
             std::vector<float> c1(nc), c2(nc);
             down(c1.data(), dC.p, nc * 4); down(c2.data(), dC2.p, nc * 4);
@@ -885,147 +884,6 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
             for (size_t i = 0; i < nc; i++) { float d = std::fabs(c1[i] - c2[i]); if (!(d <= md)) md = d; }
             *maxdiff = md;
         }
-    });
-}
-
-int ptts_debug_gemm_repeat(int32_t M, int32_t N, int32_t K, int32_t variant, int32_t epi, int32_t reps, int32_t mode, int32_t* bad_runs, float* maxdiff) {
-    return guard([&] {
-        require_device();
-        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
-        std::vector<float> ha(na), hb((size_t)N);
-        std::vector<uint16_t> hw(nw);
-        uint32_t st = 777u;
-        auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((float)(st >> 8) / 8388608.0f) - 1.0f; };
-        for (auto& x : ha) x = rnd();
-        for (auto& x : hw) { float f = rnd() * 0.05f; uint32_t u; memcpy(&u, &f, 4); x = (uint16_t)(u >> 16); }
-        for (auto& x : hb) x = rnd();
-        Tmp dA(na * 4), dA2(na * 4), dW(nw * 2), dB((size_t)N * 4), dC(nc * 4), dR(nc * 4);
-        up(dA.p, ha.data(), na * 4); up(dW.p, hw.data(), nw * 2); up(dB.p, hb.data(), (size_t)N * 4);
-        PTTS_HIP(hipMemset(dR.p, 0, nc * 4));
-        GemmArgs g;
-        g.A = dA2.as<float>(); g.amap = RowMap{K, 0, 0};
-        g.W = dW.p; g.w_bf16 = 1; g.ldw = K; g.bias = dB.as<float>();
-        g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
-        g.R = dR.as<float>(); g.epi = epi;
-        g.M = M; g.N = N; g.K = K;
-        // mode bit 0: RoPE epilogue on the first two thirds of the columns (positions m % 1024, head dim 64); bit 1: the output rows
-        // in segments of 1024 with a gap between them (the decoder's [utterance][history + T] layout)
-        const int rps = 1024;
-        std::vector<float> hcs((size_t)rps * 32), hsn((size_t)rps * 32);
-        for (size_t i = 0; i < hcs.size(); i++) { hcs[i] = std::cos(0.001f * (float)i); hsn[i] = std::sin(0.001f * (float)i); }
-        Tmp dCs(hcs.size() * 4), dSn(hsn.size() * 4);
-        up(dCs.p, hcs.data(), hcs.size() * 4); up(dSn.p, hsn.data(), hsn.size() * 4);
-        if (mode & 1) { g.rope_cos = dCs.as<float>(); g.rope_sin = dSn.as<float>(); g.rope_cols = N / 3 * 2; g.rope_hd = 64; g.rope_rows_per_seg = rps; g.epi = EPI_NONE; }
-        const size_t seg_stride = (size_t)rps * N + 4096;
-        Tmp dCseg((mode & 2) ? ((size_t)(M + rps - 1) / rps) * seg_stride * 4 : 16);
-        if (mode & 2) { g.C = dCseg.as<float>(); g.cmap = RowMap{N, rps, (int64_t)seg_stride}; g.R = nullptr; if (g.epi >= EPI_RESADD) g.epi = EPI_NONE; }
-        if (!gemm3_supported(g) || (variant >= 50 && !gemm4_supported(g))) throw Error(PTTS_EINVAL, "shape not supported");
-        std::vector<float> first(nc), cur(nc), ref, ref_nr;
-        std::vector<std::vector<float>> kept;   // PTTS_G4_VERBOSE: every run's output, compared with k_gemm3's AFTER the loop (launches before it changed the outcome)
-        const bool verbose_ref = getenv("PTTS_G4_VERBOSE") && (mode & 1) && !(mode & 2);
-        *bad_runs = 0; *maxdiff = 0.f;
-        for (int r = 0; r < reps; r++) {
-            // the operand is rewritten by a device copy right before every launch: the product reads rows another kernel has just stored
-            PTTS_HIP(hipMemsetAsync(dA2.p, 0xff, na * 4, nullptr));
-            PTTS_HIP(hipMemcpyAsync(dA2.p, dA.p, na * 4, hipMemcpyDeviceToDevice, nullptr));
-            if (variant >= 50) { g_gemm4_cfg = variant - 50; launch_gemm4(g, nullptr); g_gemm4_cfg = 0; }
-            else { g_gemm3_cfg = variant >= 30 ? variant - 30 : 0; launch_gemm3(g, nullptr); g_gemm3_cfg = 0; }
-            PTTS_HIP(hipDeviceSynchronize());
-            float* host = r ? cur.data() : first.data();
-            if (mode & 2) { for (size_t b0 = 0; b0 * rps < (size_t)M; b0++) { const size_t rows = std::min((size_t)rps, (size_t)M - b0 * rps); down(host + b0 * rps * N, dCseg.as<float>() + b0 * seg_stride, rows * N * 4); } }
-            else down(host, dC.p, nc * 4);
-            if (verbose_ref) kept.push_back(r ? cur : first);
-            if (r) {
-                float md = 0;
-                for (size_t i = 0; i < nc; i++) { float d = std::fabs(cur[i] - first[i]); if (!(d <= md)) md = d; }
-                if (md != 0.f) {
-                    (*bad_runs)++; if (md > *maxdiff) *maxdiff = md;
-                    if (getenv("PTTS_G4_VERBOSE")) {   // where the runs differ: 16 x 16 tiles (row / 16, column / 16) and a few values
-                        std::map<std::pair<int, int>, int> tiles;
-                        int shown = 0;
-                        for (size_t i = 0; i < nc; i++) if (cur[i] != first[i]) {
-                            const int row = (int)(i / N), col = (int)(i % N);
-                            tiles[{row / 16, col / 16}]++;
-                            if (shown++ < 6) {
-                                fprintf(stderr, "  run %d: C[%d][%d] = %.6f, first run %.6f", r, row, col, cur[i], first[i]);
-                                if (!ref.empty()) {
-                                    const size_t b4 = i - (col & 3);
-                                    fprintf(stderr, " | k_gemm3 %.6f; unrotated x0..x3 = %.6f %.6f %.6f %.6f; rotated (gemm3) = %.6f %.6f %.6f %.6f; this run's four = %.6f %.6f %.6f %.6f",
-                                            ref[i], ref_nr[b4], ref_nr[b4 + 1], ref_nr[b4 + 2], ref_nr[b4 + 3], ref[b4], ref[b4 + 1], ref[b4 + 2], ref[b4 + 3], cur[b4], cur[b4 + 1], cur[b4 + 2], cur[b4 + 3]);
-                                    const int pos = row % rps, j = (col % 64) >> 1;
-                                    fprintf(stderr, "; cos/sin pair = (%.6f %.6f) (%.6f %.6f)", hcs[(size_t)pos * 32 + (j & ~1)], hcs[(size_t)pos * 32 + (j | 1)], hsn[(size_t)pos * 32 + (j & ~1)], hsn[(size_t)pos * 32 + (j | 1)]);
-                                }
-                                fprintf(stderr, "\n");
-                            }
-                        }
-                        std::map<int, int> hc, hr;
-                        for (size_t i = 0; i < nc; i++) if (cur[i] != first[i]) { hc[(int)(i % N) % 256]++; hr[(int)(i / N) % 128]++; }
-                        fprintf(stderr, "  run %d: column %% 256 histogram:", r);
-                        for (auto& t : hc) fprintf(stderr, " %d:%d", t.first, t.second);
-                        fprintf(stderr, "\n  run %d: row %% 128 histogram:", r);
-                        for (auto& t : hr) fprintf(stderr, " %d:%d", t.first, t.second);
-                        fprintf(stderr, "\n");
-                        fprintf(stderr, "  run %d: %zu 16x16 tiles differ:", r, tiles.size());
-                        int k = 0;
-                        for (auto& t : tiles) { if (k++ < 24) fprintf(stderr, " (%d,%d):%d", t.first.first, t.first.second, t.second); }
-                        fprintf(stderr, "\n");
-                    }
-                }
-            }
-        }
-        if (verbose_ref) {   // which run is wrong, and what the wrong element equals
-            PTTS_HIP(hipMemcpy(dA2.p, dA.p, na * 4, hipMemcpyDeviceToDevice));
-            ref.resize(nc); ref_nr.resize(nc);
-            launch_gemm3(g, nullptr); PTTS_HIP(hipDeviceSynchronize()); down(ref.data(), dC.p, nc * 4);
-            GemmArgs h = g; h.rope_cos = h.rope_sin = nullptr;
-            launch_gemm3(h, nullptr); PTTS_HIP(hipDeviceSynchronize()); down(ref_nr.data(), dC.p, nc * 4);
-            for (size_t r = 0; r < kept.size(); r++) {
-                int shown = 0; size_t nbad = 0;
-                for (size_t i = 0; i < nc; i++) if (kept[r][i] != ref[i]) {
-                    nbad++;
-                    if (shown++ < 4) {
-                        const int row = (int)(i / N), col = (int)(i % N);
-                        const size_t b4 = i - (col & 3);
-                        const int pos = row % rps, j = (col % 64) >> 1;
-                        fprintf(stderr, "  run %zu vs k_gemm3: C[%d][%d] = %.6f want %.6f | unrotated x0..x3 = %.6f %.6f %.6f %.6f | want four = %.6f %.6f %.6f %.6f | got four = %.6f %.6f %.6f %.6f | cos (%.6f %.6f) sin (%.6f %.6f)\n",
-                                r, row, col, kept[r][i], ref[i], ref_nr[b4], ref_nr[b4 + 1], ref_nr[b4 + 2], ref_nr[b4 + 3], ref[b4], ref[b4 + 1], ref[b4 + 2], ref[b4 + 3],
-                                kept[r][b4], kept[r][b4 + 1], kept[r][b4 + 2], kept[r][b4 + 3], hcs[(size_t)pos * 32 + (j & ~1)], hcs[(size_t)pos * 32 + (j | 1)], hsn[(size_t)pos * 32 + (j & ~1)], hsn[(size_t)pos * 32 + (j | 1)]);
-                        // neighbours: the same lane's previous / next column tile and row tile
-                        if (col >= 16 && col + 16 < N && row >= 16)
-                            fprintf(stderr, "      same row, column - 16: want %.6f got %.6f unrot %.6f; column + 16: want %.6f unrot %.6f; row - 16 same column: want %.6f unrot %.6f\n",
-                                    ref[i - 16], kept[r][i - 16], ref_nr[i - 16], ref[i + 16], ref_nr[i + 16], ref[i - (size_t)16 * N], ref_nr[i - (size_t)16 * N]);
-                    }
-                }
-                fprintf(stderr, "  run %zu: %zu elements differ from k_gemm3\n", r, nbad);
-            }
-        }
-    });
-}
-
-int ptts_debug_gemm4_stamps(int32_t M, int32_t N, int32_t K, uint64_t* out /* [2][64][8][8] */) {
-    return guard([&] {
-        require_device();
-        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N, ns = 2 * 64 * 8 * 8;
-        std::vector<float> ha(na);
-        std::vector<uint16_t> hw(nw);
-        uint32_t st = 12345u;
-        auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((float)(st >> 8) / 8388608.0f) - 1.0f; };
-        for (auto& x : ha) x = rnd();
-        for (auto& x : hw) { float f = rnd() * 0.05f; uint32_t u; memcpy(&u, &f, 4); x = (uint16_t)(u >> 16); }
-        Tmp dA(na * 4), dW(nw * 2), dC(nc * 4), dS(ns * 8);
-        up(dA.p, ha.data(), na * 4); up(dW.p, hw.data(), nw * 2);
-        PTTS_HIP(hipMemset(dS.p, 0, ns * 8));
-        GemmArgs g;
-        g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
-        g.W = dW.p; g.w_bf16 = 1; g.ldw = K;
-        g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
-        g.M = M; g.N = N; g.K = K;
-        if (!gemm4_supported(g)) throw Error(PTTS_EINVAL, "shape not supported by k_gemm4");
-        for (int i = 0; i < 3; i++) launch_gemm4(g, nullptr);
-        g.dbg = dS.as<unsigned long long>();
-        launch_gemm4(g, nullptr);
-        PTTS_HIP(hipDeviceSynchronize());
-        down(out, dS.p, ns * 8);
     });
 }
 

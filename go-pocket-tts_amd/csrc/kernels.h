@@ -54,26 +54,11 @@ struct GemmArgs {
     // [z kslice, (z+1) kslice) and stores its raw sums at C + z * zstride (no bias, no epilogue: the consumer adds the planes)
     int kslice = 0; int64_t zstride = 0;
     float* tail = nullptr;           // k_skinny only: the LAST column goes, as acc + bias without the epilogue, to tail[m] instead of C
-    // ---- k_skinny only: split-plane activations between the launches of an AR step ------------------------------------------
-    // A value x travels as two bf16 planes hi + lo with x = hi + lo to ~2^-17 (what every kernel of the step feeds the matrix
-    // cores with): the PRODUCER splits once in its epilogue, the consumer's prologue is then a plain copy into LDS instead of
-    // load + convert + split on 16 waves (measured: the conversion work sits on the critical path of every launch).
-    const uint16_t* Ah = nullptr; const uint16_t* Al = nullptr;   // A as planes, dense [M][K]; A itself is then not read
-    uint16_t* Ch = nullptr; uint16_t* Cl = nullptr; int64_t cpl_ld = 0;   // the epilogue's values as planes [M][cpl_ld] (besides C, or instead of it: C == null)
-    const float* cpl_scale = nullptr;   // [N] or null: the planes hold value * cpl_scale[n] -- the weight of the LayerNorm the consumer folds in
-    // LayerNorm moved from the consumer's prologue into its EPILOGUE (the consumer multiplies x*g as it stands):
-    //   LN(x) W^T = rstd * ((x*g) W^T - mean * wg) + wb,   wg[n] = sum_k g[k] W[n][k],  wb[n] = sum_k b[k] W[n][k]
-    // the producer of x leaves per-row partial sums (sum x, sum x^2 per 16-column group) next to the planes, the consumer
-    // turns them into mean / rstd while its weight loads are in flight
-    float* stats_out = nullptr;                          // producer: [M][ceil(N / 16)][2]
-    const float* stats_in = nullptr; int stats_n = 0;   // consumer: stats_n partials per row (<= 64), row width = K
-    const float* wg = nullptr; const float* wb = nullptr; float ln_eps = 1e-5f;
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
-    unsigned long long* dbg = nullptr;   // k_gemm4 stamps (tools/stamps_gemm4.py only; null in the product)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t stream);
-bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream);   // a product with the RoPE epilogue (GemmArgs::rope_cos): k_gemm4 or k_gemm3; false: no kernel takes it (the caller rotates in a second launch)   // picks k_gemm2 (bf16-split MFMA) when the shape allows, else the exact-f32 k_gemm
+bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream);   // a product with the RoPE epilogue (GemmArgs::rope_cos) on k_gemm3; false: the shape is not taken (the caller rotates in a second launch)
 bool gemm_wres_supported(const GemmArgs& a);   // gemm_wres.hip: K, N <= 256 with the whole weight matrix resident in LDS
 void launch_gemm_wres(const GemmArgs& a, hipStream_t stream);
 bool gemm2_supported(const GemmArgs& a);
@@ -81,9 +66,6 @@ void launch_gemm2(const GemmArgs& a, hipStream_t stream);
 bool gemm3_supported(const GemmArgs& a);   // direct-to-register activations, 256-row blocks (gemm3.hip)
 void launch_gemm3(const GemmArgs& a, hipStream_t stream);
 extern thread_local int g_gemm3_cfg;
-bool gemm4_supported(const GemmArgs& a);   // both operands through LDS by LDS-DMA, 128-row x 256-column blocks (gemm4.hip): K >= 256, N % 256 == 0, bf16 weights
-void launch_gemm4(const GemmArgs& a, hipStream_t stream);
-extern thread_local int g_gemm4_cfg;
 
 // Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.
@@ -133,19 +115,6 @@ struct LnArgs {
     const float* pscale = nullptr;
 };
 void launch_layernorm(const LnArgs& a, hipStream_t stream);
-// AR step, once per row instead of once per consumer block: x_out = x + (sum_z partial[z] + pbias) (fixed order), then LayerNorm of
-// the updated row -> y_out (f32, optional) and the row as split planes yh / yl (bf16 hi + lo) for the next linear's matrix cores.
-// The fused prologue of the step linear did this on every one of its 48-64 column blocks, 16 rows per block on 16 waves: measured
-// 3-6 us of vector work on the critical path of the launch (profiles/r2_step_stamps_before.txt).  d % 4 == 0, d <= 4096.
-struct CombineLnArgs {
-    const float* x = nullptr;
-    const float* partial = nullptr; int splitk = 0; int64_t pstride = 0; const float* pbias = nullptr;
-    float* x_out = nullptr;                      // null: x is not updated (partial == null)
-    const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
-    float* y_out = nullptr; uint16_t* yh = nullptr; uint16_t* yl = nullptr;
-    int rows = 0, d = 0;
-};
-void launch_combine_ln(const CombineLnArgs& a, hipStream_t stream);
 // Bessel-variance "RMS" norm of the timestep embedder (tensor_util.go:273-326), in place
 void launch_rmsnorm_alpha(float* x, const float* alpha, float eps, int rows, int d, hipStream_t stream);
 
@@ -186,7 +155,6 @@ struct AttnArgs {
     const int32_t* seg_len = nullptr;   // if set (AR step): pos = seg_len[seg], rope+append fused
     int context = -1;                   // keys j with pos-context < j <= pos   (attention.go:473-484)
     float* out = nullptr; int64_t out_ld = 0;  // out + rowaddr(row) + h*hd
-    uint16_t* out_h = nullptr; uint16_t* out_l = nullptr;   // fused step only: the output as split planes (bf16 hi + lo, same ld) instead of f32 -- what the out_proj launch stages
     int64_t o_rows_per_batch = 0, o_batch_stride = 0;
     int rows = 0, heads = 0, hd = 64;
     int max_keys = 0;                   // upper bound on keys per query (sizes the LDS score buffer)

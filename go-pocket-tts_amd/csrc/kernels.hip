@@ -142,22 +142,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
     }
 }
 
-// k_gemm4 (gemm4.hip: both operands through LDS by LDS-DMA) is NOT in the default path: PTTS_GEMM4 = 1 (persistent form), 2 (two-stage
-// form), 3 (by shape) select it for measurements.  It is 5-10 % faster than k_gemm3 on the decoder's deep shapes (profiles/
-// r2_gemm4_microbench.txt: 0.25 ms of 15.3 per batch) and bit-equal to it in every direct comparison, but its two-stage form with
-// the RoPE epilogue gave run-to-run differences (single columns of 16-row tiles, timing dependent, cause not established:
-// DESIGN.md "What the measurements changed (round 2)") -- a kernel with an unexplained failure does not ship for 2 % of one phase.
-static bool try_gemm4(const GemmArgs& a, hipStream_t stream) {
-    static const int g4 = [] { const char* e = getenv("PTTS_GEMM4"); return e ? atoi(e) : 0; }();
-    if (!g4 || !gemm4_supported(a)) return false;
-    g_gemm4_cfg = g4 == 3 ? (a.N > 512 ? 1 : 0) : (g4 == 2 ? 1 : 0);
-    launch_gemm4(a, stream);
-    g_gemm4_cfg = 0;
-    return true;
-}
-
 bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream) {
-    if (try_gemm4(a, stream)) return true;
     if (!gemm3_supported(a)) return false;
     launch_gemm3(a, stream);
     return true;
@@ -171,7 +156,6 @@ void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 64 && a.Wt && skinny_supported(a, 1)) { launch_skinny(a, SkinnyFuse{}, 1, nullptr, stream); return; }
     static const int wres = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 1; }();   // A/B measurement
     if (wres && force != 2 && gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
-    if (force != 2 && try_gemm4(a, stream)) return;
     if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     note_launch("k_gemm");

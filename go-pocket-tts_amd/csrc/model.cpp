@@ -189,24 +189,6 @@ struct Walker {
         }
         return rm;
     }
-    // LayerNorm folded into the following linear's epilogue: (g W^T, b W^T)
-    void folded_norm(const std::string& lin_name, const std::string& norm_name, size_t* wg, size_t* wb) {
-        const std::string wn = lin_name + ".weight";
-        const size_t out = (size_t)shape(wn)[0], in = (size_t)shape(wn)[1];
-        std::vector<double> g, b;
-        if (host) {
-            std::vector<float> W = effective_weights(wn), gw = load(norm_name + ".weight"), gb = load(norm_name + ".bias");
-            g.assign(out, 0.0); b.assign(out, 0.0);
-            for (size_t n = 0; n < out; n++) {
-                double sg = 0.0, sb = 0.0;
-                for (size_t k = 0; k < in; k++) { sg += (double)gw[k] * (double)W[n * in + k]; sb += (double)gb[k] * (double)W[n * in + k]; }
-                g[n] = sg; b[n] = sb;
-            }
-        }
-        *wg = add_f32(out, [&](float* dst) { for (size_t n = 0; n < out; n++) dst[n] = (float)g[n]; });
-        *wb = add_f32(out, [&](float* dst) { for (size_t n = 0; n < out; n++) dst[n] = (float)b[n]; });
-    }
-
     Lin step_linear(const std::string& name, bool with_bias) {
         if (!i8w) {
             Lin l = linear(name, with_bias);
@@ -345,7 +327,6 @@ struct Walker {
             L.out_proj = step_linear(p + ".self_attn.out_proj", false);
             L.l1 = step_linear(p + ".linear1", false);
             L.l2 = step_linear(p + ".linear2", false);
-            folded_norm(p + ".linear1", p + ".norm2", &L.l1_wg, &L.l1_wb);
             if (L.out_proj.out % d.heads) throw Error(PTTS_EFORMAT, strfmt("native: d_model %d not divisible by num_heads %d", L.out_proj.out, d.heads));
             d.n_layers++;
         }

@@ -38,7 +38,6 @@ struct Desc {
         Norm n1, n2; Lin in_proj, out_proj, l1, l2;
         // norm2 folded into linear1's epilogue (kernels.h GemmArgs::stats_in): wg[n] = sum_k g[k] W[n][k], wb[n] = sum_k b[k] W[n][k]
         // over the weights as the step computes with them (f64 sums, stored f32)
-        size_t l1_wg = NONE, l1_wb = NONE;
     } layers[MAX_LAYERS];
     // flow_net (flow_net.go:242-248)
     int flow_dim = 0, flow_depth = 0, nfreq = 0;

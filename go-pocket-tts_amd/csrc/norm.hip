@@ -1,5 +1,7 @@
 // norm.hip -- LayerNorm (K3; linear.go:265-329 / nn_ops.go:79-149) with the adaLN modulation of the flow net (K11)
 // and the split-K reduction + residual update of the AR step fused in front.
+#include "../../include/ptts.h"
+#include "common.h"
 #include "kernels.h"
 #include "device_util.h"
 
@@ -102,87 +104,6 @@ __global__ __launch_bounds__(256) void k_layernorm_reg(LnArgs a) {
     }
 }
 
-typedef __bf16 nbf16x2 __attribute__((ext_vector_type(2)));
-typedef float nf32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void nsplit2(float a, float b, unsigned& hi, unsigned& lo) {   // as skinny.hip split2
-    nf32x2 f = {a, b};
-    nbf16x2 h = __builtin_convertvector(f, nbf16x2);
-    nf32x2 r = f - __builtin_convertvector(h, nf32x2);
-    nbf16x2 l = __builtin_convertvector(r, nbf16x2);
-    hi = *reinterpret_cast<unsigned*>(&h);
-    lo = *reinterpret_cast<unsigned*>(&l);
-}
-
-// one block per row, thread t owns the float4 columns t + 256 j
-__global__ __launch_bounds__(256) void k_combine_ln(CombineLnArgs a) {
-    __shared__ float red[8];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nv = a.d >> 2;
-    const float* xr = a.x + (int64_t)row * a.d;
-    float4 v[4];
-    float4 lw[4], lb[4];
-    bool ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int f = tid + 256 * j;
-        ok[j] = f < nv;
-        const int fc = ok[j] ? f : 0;
-        v[j] = reinterpret_cast<const float4*>(xr)[fc];
-        lw[j] = a.ln_w ? reinterpret_cast<const float4*>(a.ln_w)[fc] : make_float4(1.f, 1.f, 1.f, 1.f);
-        lb[j] = a.ln_b ? reinterpret_cast<const float4*>(a.ln_b)[fc] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.partial) {   // the linear's output is summed first (planes in order, then the bias), then added to x: y = W h + b; x += y
-            float4 acc = reinterpret_cast<const float4*>(a.partial + (int64_t)row * a.d)[fc];
-            for (int z = 1; z < a.splitk; z++) {
-                const float4 p = reinterpret_cast<const float4*>(a.partial + (int64_t)z * a.pstride + (int64_t)row * a.d)[fc];
-                acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w;
-            }
-            if (a.pbias) { const float4 b = reinterpret_cast<const float4*>(a.pbias)[fc]; acc.x += b.x; acc.y += b.y; acc.z += b.z; acc.w += b.w; }
-            v[j].x += acc.x; v[j].y += acc.y; v[j].z += acc.z; v[j].w += acc.w;
-            if (ok[j] && a.x_out) reinterpret_cast<float4*>(a.x_out + (int64_t)row * a.d)[f] = v[j];
-        }
-        if (!ok[j]) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; j++) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
-    s = wave_sum_dpp(s);
-    if (lane == 0) red[wave] = s;
-    __syncthreads();
-    const float rk = 1.0f / (float)a.d;
-    const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * rk;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-        if (ok[j]) { const float d0 = v[j].x - mean, d1 = v[j].y - mean, d2 = v[j].z - mean, d3 = v[j].w - mean; q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3); }
-    q = wave_sum_dpp(q);
-    if (lane == 0) red[4 + wave] = q;
-    __syncthreads();
-    const float inv_std = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * rk + a.eps);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        const int f = tid + 256 * j;
-        if (!ok[j]) continue;
-        float4 o;
-        o.x = (v[j].x - mean) * inv_std * lw[j].x + lb[j].x; o.y = (v[j].y - mean) * inv_std * lw[j].y + lb[j].y;
-        o.z = (v[j].z - mean) * inv_std * lw[j].z + lb[j].z; o.w = (v[j].w - mean) * inv_std * lw[j].w + lb[j].w;
-        if (a.y_out) reinterpret_cast<float4*>(a.y_out + (int64_t)row * a.d)[f] = o;
-        if (a.yh) {
-            unsigned h01, l01, h23, l23;
-            nsplit2(o.x, o.y, h01, l01);
-            nsplit2(o.z, o.w, h23, l23);
-            reinterpret_cast<uint2*>(a.yh + (int64_t)row * a.d)[f] = make_uint2(h01, h23);
-            reinterpret_cast<uint2*>(a.yl + (int64_t)row * a.d)[f] = make_uint2(l01, l23);
-        }
-    }
-}
-
-void launch_combine_ln(const CombineLnArgs& a, hipStream_t stream) {
-    note_launch("k_combine_ln");
-    if (a.rows <= 0) return;
-    if (a.d % 4 || a.d > 4096 || !aligned16(a.x) || (a.partial && !aligned16(a.partial))) abort();   // step shapes always qualify (checked by the caller)
-    hipLaunchKernelGGL(k_combine_ln, dim3(a.rows), dim3(256), 0, stream, a);
-}
-
 void launch_layernorm(const LnArgs& a, hipStream_t stream) {
     note_launch("k_layernorm");
     if (a.rows <= 0) return;
@@ -190,7 +111,7 @@ void launch_layernorm(const LnArgs& a, hipStream_t stream) {
                (!a.y || aligned16(a.y)) && (!a.shift || (a.ldmod % 4 == 0 && aligned16(a.shift) && aligned16(a.scale))) &&
                (!a.w || aligned16(a.w)) && (!a.b || aligned16(a.b));
     if (reg) hipLaunchKernelGGL(k_layernorm_reg, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
-    else if (a.partial) abort();   // the fused reduction exists in the register kernel only (step shapes always qualify)
+    else if (a.partial) throw Error(PTTS_EINVAL, "ptts-hip: internal: the fused split-K reduction needs rows of d % 4 == 0, d <= 1024, 16-byte aligned");   // register kernel only
     else hipLaunchKernelGGL(k_layernorm, dim3((a.rows + 3) / 4), dim3(256), 0, stream, a);
 }
 

@@ -10,7 +10,6 @@
 
 namespace ptts {
 
-constexpr int SK_PLANE_KMAX = 1024;   // widest row a plane edge of the step carries through the one-slice step kernel
 static RowMap flat(int64_t ld) { return RowMap{ld, 0, 0}; }
 static RowMap seg(int64_t ld, int64_t rows_per_batch, int64_t batch_stride) { return RowMap{ld, rows_per_batch, batch_stride}; }
 
@@ -223,16 +222,6 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     b->fx.ensure(B * d.flow_dim * f); b->fh.ensure(B * d.flow_dim * f); b->fh2.ensure(B * d.flow_dim * f);
     b->cur.ensure(B * d.ldim * f);
     b->partial.ensure((size_t)16 * B * std::max(d.d_model, d.flow_dim) * f);
-    {
-        const size_t D = (size_t)d.d_model, F = (size_t)d.ffn, C = (size_t)d.flow_dim;
-        auto al = [](size_t n) { return (n + 127) & ~(size_t)127; };
-        const size_t nD = al(B * D * 2), nF = al(B * F * 2), nC = al(B * C * 2), nS = al(B * ((D + 15) / 16) * 2 * f);
-        b->planes.ensure(6 * nD + 2 * nF + 4 * nC + nS);
-        char* p = (char*)b->planes.p;
-        auto take = [&](Batch::Planes& pl, size_t n) { pl.h = (uint16_t*)p; p += n; pl.l = (uint16_t*)p; p += n; };
-        take(b->pl_x, nD); take(b->pl_attn, nD); take(b->pl_xg, nD); take(b->pl_ff, nF); take(b->pl_sy, nC); take(b->pl_fh, nC);
-        b->ln_stats = (float*)p;
-    }
     b->latents.ensure(B * b->max_steps * d.ldim * f);
     {
         StepFinish sf{b->st, b->eos.as<float>(), b->latents.as<float>(), (int64_t)b->max_steps * d.ldim, (int32_t)d.ldim};
@@ -477,7 +466,7 @@ static void step_gemm(Model& m, const GemmArgs& g, const SkinnyFuse& fu = Skinny
     if (!st) st = m.stream;
     const bool fused = fu.partial || fu.ln;
     const bool sk = fused ? skinny_fuse_supported(g, fu) : skinny_supported(g, splitk);
-    if (!sk && (splitk > 1 || fused || g.Ah || g.Ch || g.stats_out || g.stats_in)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the step kernel");
+    if (!sk && (splitk > 1 || fused)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the step kernel");
     Prof& p = m.prof;
     if (p.on) {
         while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
@@ -586,165 +575,7 @@ void step_open(Batch& b) {
                       b.in32.as<float>(), b.cur.as<float>(), ok ? &lin : nullptr, m.stream);
 }
 
-// The same step with every activation edge between two launches carried as split planes (x = bf16 hi + lo), written once by
-// the producer's epilogue, and with the LayerNorms taken off the consumers' critical path:
-//   norm1 / out_norm (their input still needs the pending split-K sum): one small launch per step and layer does sum + residual
-//       + LayerNorm + split for the 64 rows ONCE (k_combine_ln) instead of every column block of the next linear redoing it;
-//   norm2: folded into linear1's epilogue -- out_proj leaves x * g as planes and per-row partial sums, linear1 multiplies the
-//       planes as they are and applies rstd * (acc - mean * wg) + wb to its sums.
-// Measured motive (profiles/r2_step_stamps_before.txt): a fused-prologue step linear spent 3-6 us converting and normalising
-// its 16 rows on 16 waves (vector-issue bound) before its first matrix instruction.  PTTS_STEP_V1=1 keeps the old plan (A/B).
-static bool step_core_v2(Batch& b, int lsd, bool opened, bool fuse_finish) {
-    bool finished = false;
-    Model& m = *b.m;
-    const Desc& d = m.d;
-    hipStream_t s = m.stream;
-    const int B = b.B, D = d.d_model, C = d.flow_dim, NA = d.ada_all.out;
-    const bool kvb = m.opts.kv == PTTS_KV_BF16;
-    float* x = b.x.as<float>();
-    float* x_alt = b.x2.as<float>();
-    float* qkv = b.qkv.as<float>();
-    if (!opened) step_gemm(m, mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B));
-    auto planes_in = [](GemmArgs& g, const Batch::Planes& p) { g.A = nullptr; g.Ah = p.h; g.Al = p.l; };
-    auto planes_out = [](GemmArgs& g, const Batch::Planes& p, int64_t ld) { g.Ch = p.h; g.Cl = p.l; g.cpl_ld = ld; };
-    Pending pend;
-    auto combine = [&](const Norm& n, float* y_out) {   // x (+ pending split-K sum) -> LayerNorm -> pl_x (+ y_out)
-        CombineLnArgs c;
-        c.x = x; c.partial = pend.partial; c.splitk = pend.splitk; c.pstride = pend.pstride; c.pbias = pend.bias;
-        c.x_out = pend.partial ? x_alt : nullptr;
-        c.ln_w = m.at<float>(n.w); c.ln_b = m.at<float>(n.b); c.eps = n.eps;
-        c.y_out = y_out; c.yh = b.pl_x.h; c.yl = b.pl_x.l;
-        c.rows = B; c.d = D;
-        launch_combine_ln(c, s);
-        if (pend.partial) std::swap(x, x_alt);
-        pend = Pending{};
-    };
-    for (int l = 0; l < d.n_layers; l++) {
-        const auto& L = d.layers[l];
-        combine(L.n1, nullptr);
-        {
-            GemmArgs g = mk(m, nullptr, flat(D), L.in_proj, qkv, flat(3 * D), B);
-            planes_in(g, b.pl_x);
-            step_gemm(m, g);
-        }
-        AttnArgs a;
-        a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
-        a.k_seg_stride = (int64_t)d.heads * b.cap * d.hd; a.k_head_stride = (int64_t)b.cap * d.hd; a.k_row_stride = d.hd;
-        a.seg_len = b.st.kv_len; a.active = b.st.active;
-        a.context = -1;
-        a.out = b.attn.as<float>(); a.out_ld = D;
-        a.rows = B; a.heads = d.heads; a.max_keys = b.cap;
-        a.keys_now = b.capturing ? b.capture_keys : b.kv_bound + 1;
-        a.fused_step = 1; a.qkv = qkv; a.qkv_ld = 3 * D; a.d_model = D;
-        a.cos_t = m.at<float>(d.rope_cos); a.sin_t = m.at<float>(d.rope_sin); a.cap = b.cap;
-        a.pre_k = b.pre_k.as<const void*>(); a.pre_v = b.pre_v.as<const void*>(); a.pre_len = b.pre_len.as<int32_t>(); a.layer = l;
-        // the one-burst step attention leaves its output as planes; a cache beyond its reach (f32 keys past 256) takes the generic
-        // kernel, whose f32 rows out_proj then stages itself
-        const bool attn_planes = attn_step_supported(a);
-        if (attn_planes) { a.out_h = b.pl_attn.h; a.out_l = b.pl_attn.l; }
-        launch_attention(a, s);
-        {   // x += out_proj(attn); the same values times norm2.weight leave as planes, with the rows' partial sums
-            GemmArgs go = mk(m, b.attn.as<float>(), flat(D), L.out_proj, x, flat(D), B);
-            if (attn_planes) planes_in(go, b.pl_attn);
-            go.R = x; go.epi = EPI_RESADD;
-            planes_out(go, b.pl_xg, D);
-            go.cpl_scale = m.at<float>(L.n2.w);
-            go.stats_out = b.ln_stats;
-            step_gemm(m, go);
-        }
-        {   // GELU(linear1(norm2(x))) with the norm applied to the sums; the result exists as planes only
-            GemmArgs g1 = mk(m, nullptr, flat(D), L.l1, nullptr, flat(d.ffn), B);
-            planes_in(g1, b.pl_xg);
-            g1.stats_in = b.ln_stats; g1.stats_n = (D + 15) / 16; g1.wg = m.at<float>(L.l1_wg); g1.wb = m.at<float>(L.l1_wb); g1.ln_eps = L.n2.eps;
-            g1.epi = EPI_GELU;
-            planes_out(g1, b.pl_ff, d.ffn);
-            step_gemm(m, g1);
-        }
-        {
-            GemmArgs g2 = mk(m, nullptr, flat(d.ffn), L.l2, x, flat(D), B);
-            planes_in(g2, b.pl_ff);
-            const int S = pick_split(B, D, d.ffn, g2.w_bf16 != 0 || g2.wt_i8 != 0);
-            if (S > 1) {
-                step_gemm(m, g2, SkinnyFuse{}, S, b.partial.as<float>());
-                pend.partial = b.partial.as<float>(); pend.splitk = S; pend.pstride = (int64_t)B * D; pend.bias = m.at<float>(L.l2.b);
-            } else {
-                g2.R = x; g2.epi = EPI_RESADD;
-                step_gemm(m, g2);
-            }
-        }
-    }
-    float* last = b.last.as<float>();
-    float* sy = b.sy.as<float>();
-    const float* tc = m.tcomb.at(lsd)->as<float>();
-    combine(d.out_norm, last);   // out_norm rows: f32 for later Euler steps and the staged API, planes for the launch below
-    {   // columns 0..C-1 = cond_embed (SiLU epilogue, also as planes for the adaLN launch), column C = out_eos (raw)
-        GemmArgs g = mk(m, nullptr, flat(D), d.cond_eos, sy, flat(C), B);
-        planes_in(g, b.pl_x);
-        g.epi = EPI_SILU; g.addvec = tc; g.tail = b.eos.as<float>();
-        planes_out(g, b.pl_sy, C);
-        step_gemm(m, g);
-    }
-    float* ada = b.ada.as<float>();
-    float* fx = b.fx.as<float>();
-    float* cur = b.cur.as<float>();
-    for (int i = 0; i < lsd; i++) {
-        if (i > 0) {
-            GemmArgs gc = mk(m, last, flat(D), d.cond_embed, sy, flat(C), B);  // sy = silu(0.5*(e_s+e_t) + cond_embed(c))
-            gc.epi = EPI_SILU; gc.addvec = tc + (size_t)i * C;
-            planes_out(gc, b.pl_sy, C);
-            step_gemm(m, gc);
-        }
-        {
-            GemmArgs ga = mk(m, nullptr, flat(C), d.ada_all, ada, flat(NA), B);
-            planes_in(ga, b.pl_sy);
-            step_gemm(m, ga);
-        }
-        if (i > 0 || !opened) step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
-        for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
-            const auto& rb = d.rb[r];
-            {   // modulated LayerNorm stays in the prologue (its shift / scale are per row: nothing to fold); SiLU output as planes only
-                GemmArgs g0 = mk(m, fx, flat(C), rb.mlp0, nullptr, flat(C), B);
-                g0.epi = EPI_SILU;
-                planes_out(g0, b.pl_fh, C);
-                SkinnyFuse fu;
-                fu.ln = 1; fu.eps = rb.ln.eps; fu.ln_w = m.at<float>(rb.ln.w); fu.ln_b = m.at<float>(rb.ln.b);
-                fu.shift = ada + (size_t)r * 3 * C; fu.scale = fu.shift + C; fu.ldmod = NA;
-                step_gemm(m, g0, fu);
-            }
-            GemmArgs g2 = mk(m, nullptr, flat(C), rb.mlp2, fx, flat(C), B);
-            planes_in(g2, b.pl_fh);
-            g2.R = fx; g2.epi = EPI_GATE_RESADD; g2.gate = ada + (size_t)r * 3 * C + 2 * C; g2.ldg = NA;
-            step_gemm(m, g2);
-        }
-        FusedIn fin;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
-        fin.affine = false; fin.eps = 1e-6f;
-        fin.shift = ada + (size_t)d.flow_depth * 3 * C; fin.scale = fin.shift + C; fin.ldmod = NA;
-        if (fuse_finish && i == lsd - 1) fin.finish = b.fin_dev.as<StepFinish>();
-        finished = step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd);  // current += flow / steps
-    }
-    if (!b.capturing) b.kv_bound++;   // every live slot has appended one key
-    return finished;
-}
-
-// Which plan runs.  Measured on MI355X at batch 64 / bf16, same box, alternating (profiles/r2_step_plan_ab.txt; per-kernel tables
-// profiles/r2_step_plan_v{1,2}_by_grid.txt): plan 0 (no plane edges) 57.67 / 57.45 ms per batch, plan 1 (planes on the flow net's
-// mlp0 -> mlp2 edge only) 57.76 / 57.75, plan 2 (every edge) 57.99 / 58.26.  The plane plan does NOT pay: in_proj drops 9.1 -> 7.2 us
-// but its k_combine_ln launch costs 4.5 (a dependent launch that reads what other XCDs just wrote never gets under ~4.5 us),
-// linear1 with the norm folded away stays at 8.6-8.9 (the fused prologue is vector-issue bound, but it runs under the wave's own
-// weight fetch), 2-byte plane stores cost the attention launch 0.8 us.  Plans 1 and 2 stay selectable (ptts_opts.step_plan,
-// PTTS_STEP_PLAN) and under test as the record of the experiment; the default is plan 0.
-static bool step_v2_ok(const Batch& b) {
-    const Desc& d = b.m->d;
-    static const int env_plan = [] { const char* e = getenv("PTTS_STEP_PLAN"); return e ? atoi(e) : -1; }();
-    const int plan = env_plan >= 0 ? env_plan : b.m->opts.step_plan;
-    if (plan != 2 || b.B > 64 || d.cond_eos.wt == NONE || d.d_model % 16 || d.d_model > 1024 || d.ffn % 8 || d.flow_dim % 8 || d.flow_dim > 1024) return false;
-    for (int l = 0; l < d.n_layers; l++)
-        if (d.layers[l].l1_wg == NONE || d.layers[l].in_proj.wt == NONE || d.layers[l].l2.in != d.ffn || d.layers[l].l1.in != d.d_model) return false;
-    return true;
-}
-
 bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
-    if (step_v2_ok(b)) return step_core_v2(b, lsd, opened, fuse_finish);
     bool finished = false;
     Model& m = *b.m;
     const Desc& d = m.d;
@@ -855,24 +686,6 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         if (i > 0 || !opened) step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
         for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
             const auto& rb = d.rb[r];
-            static const int env_plan = [] { const char* e = getenv("PTTS_STEP_PLAN"); return e ? atoi(e) : -1; }();
-            const bool edge = (env_plan >= 0 ? env_plan : m.opts.step_plan) == 1 && C % 8 == 0 && C <= SK_PLANE_KMAX;
-            if (edge) {   // mlp0's SiLU output travels to mlp2 as split planes (written once, copied straight into mlp2's LDS image)
-                GemmArgs g0 = mk(m, fx, flat(C), rb.mlp0, nullptr, flat(C), B);
-                g0.epi = EPI_SILU;
-                g0.Ch = b.pl_fh.h; g0.Cl = b.pl_fh.l; g0.cpl_ld = C;
-                SkinnyFuse fu;
-                fu.ln = 1; fu.eps = rb.ln.eps; fu.ln_w = m.at<float>(rb.ln.w); fu.ln_b = m.at<float>(rb.ln.b);
-                fu.shift = ada + (size_t)r * 3 * C; fu.scale = fu.shift + C; fu.ldmod = NA;
-                GemmArgs g2 = mk(m, nullptr, flat(C), rb.mlp2, fx, flat(C), B);
-                g2.Ah = b.pl_fh.h; g2.Al = b.pl_fh.l;
-                g2.R = fx; g2.epi = EPI_GATE_RESADD; g2.gate = ada + (size_t)r * 3 * C + 2 * C; g2.ldg = NA;
-                if (skinny_fuse_supported(g0, fu) && skinny_supported(g2, 1)) {
-                    step_gemm(m, g0, fu);
-                    step_gemm(m, g2);
-                    continue;
-                }
-            }
             FusedIn in;
             in.norm = &rb.ln; in.eps = rb.ln.eps;
             in.shift = ada + (size_t)r * 3 * C; in.scale = in.shift + C; in.ldmod = NA;

@@ -106,11 +106,6 @@ struct Batch {
     std::vector<int32_t> pre_len_host;
     // step workspace
     DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step, partial, x2;
-    // split-plane activations between the launches of a step (kernels.h GemmArgs::Ah): bf16 hi + lo per value, one region per edge
-    DevBuf planes;
-    struct Planes { uint16_t *h = nullptr, *l = nullptr; };
-    Planes pl_x, pl_attn, pl_xg, pl_ff, pl_sy, pl_fh;   // LN1 / out_norm rows, attention output, x * norm2.weight, GELU(linear1), silu(cond), flow hidden
-    float* ln_stats = nullptr;                          // [B][d_model / 16][2]: partial sum / sum of squares of the rows linear1 normalises
     DevBuf latents;          // [B][max_steps][ldim]
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;

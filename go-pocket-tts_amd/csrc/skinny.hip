@@ -68,8 +68,7 @@ constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_TWO 
 // not hold its eight registers (the fused-prologue variants sit at the 128-register limit of a 16-wave block)
 // WT: how the weights are stored -- 0: f32, 1: bf16, 2: per-row-scaled int8 (offset-binary bytes; converted to bf16 in registers,
 // which is exact for [-127, 127]; the row scale is applied to the sums in the epilogue)
-// APL: the activations arrive as split planes (GemmArgs::Ah / Al; PRO == 0 only): the prologue is a copy into the LDS image
-template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false, bool APL = false>
+template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false>
 __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_m, int p_n, int p_k, int splitk, GemmArgs a, SkinnyFuse fu,
                                                  float* partial, unsigned long long* stamps) {
     // The seven leading scalars (copies of a.Wt, a.A, a.amap.ld, a.M, a.N, a.K, and the split) are what the weight and
@@ -85,7 +84,6 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     constexpr int RB = NJ > 4 ? 4096 : 2048, CMASK = RB / 16 - 1;   // bytes and 16-byte chunks (- 1) per image row
     __shared__ __attribute__((aligned(16))) unsigned char Xh[16 * RB];
     __shared__ __attribute__((aligned(16))) unsigned char Xl[16 * RB];
-    __shared__ float ln_mu[16], ln_rs[16];   // LayerNorm folded into the epilogue (GemmArgs::stats_in): mean and 1/std of the tile's rows
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches
     constexpr int KP = 16 / CG;                // K parts per column group
     const int cg = wave % CG, kq4 = wave / CG;
@@ -125,14 +123,6 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     float e_bias = 0.f, e_addv = 0.f, e_scl = 1.f, e_r[4] = {0.f, 0.f, 0.f, 0.f}, e_g[4] = {0.f, 0.f, 0.f, 0.f};
     float e_ws = 1.0f;   // int8 weights: the scale of this lane's output column
     if constexpr (WT == 2) { if (kq4 == 0) e_ws = a.wscale[n_ok ? n : 0]; }
-    float e_wg = 0.f, e_wb = 0.f, e_cs = 1.f;   // folded LayerNorm (wg, wb of this column), scale of the output planes
-    if constexpr (PRO == 0) {
-        if (kq4 == 0 && splitk <= 1) {
-            const int nc = n_ok ? n : 0;
-            if (a.stats_in) { e_wg = a.wg[nc]; e_wb = a.wb[nc]; }
-            if (a.cpl_scale) e_cs = a.cpl_scale[nc];
-        }
-    }
     if (kq4 == 0 && splitk <= 1) {
         const int nc = n_ok ? n : 0;
         if (a.bias) e_bias = a.bias[nc];
@@ -177,48 +167,6 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     // it uses (16 waves per CU leave 128 VGPRs per lane).
     // A wave whose row does not exist (batch not a multiple of 16: batch 1 has 15 of them) skips the prologue altogether: its
     // LDS row feeds only output rows that are never stored, and the SIMD it shares is left to the waves with real rows.
-    if constexpr (PRO == 0) {
-        // folded LayerNorm: wave w turns the producer's partial sums of row w into mean and 1/std (one load, two wave sums)
-        if (a.stats_in && m0 + wave < p_m) {
-            const float2 p = lane < a.stats_n ? reinterpret_cast<const float2*>(a.stats_in)[(int64_t)(m0 + wave) * a.stats_n + lane] : make_float2(0.f, 0.f);
-            const float rk = __builtin_amdgcn_rcpf((float)p_k);
-            const float mean = wave_sum_dpp(p.x) * rk;
-            const float var = wave_sum_dpp(p.y) * rk - mean * mean;
-            if (lane == 0) { ln_mu[wave] = mean; ln_rs[wave] = __builtin_amdgcn_rsqf(fmaxf(var, 0.f) + a.ln_eps); }
-        }
-    }
-    if constexpr (APL) {
-        if (m0 + wave < p_m) {
-            // the row's planes are bf16 [K]: chunk c = 8 consecutive k = 16 bytes, lane owns chunks lane + 64 j -- exactly the unit
-            // of the LDS image, so the prologue is load + store (swizzled chunk index), no arithmetic
-            constexpr int NCH = (NJ + 1) / 2;
-            const int64_t rowc = ((int64_t)(m0 + wave) * p_k + k_begin) >> 3;
-            uint4 vh[NCH], vl[NCH];
-            int cc[NCH];
-            bool cok[NCH];
-#pragma unroll
-            for (int j = 0; j < NCH; j++) {
-                const int c = lane + 64 * j;
-                cok[j] = c * 8 < klen;
-                cc[j] = cok[j] ? c : 0;
-                vh[j] = reinterpret_cast<const uint4*>(a.Ah)[rowc + cc[j]];
-                vl[j] = reinterpret_cast<const uint4*>(a.Al)[rowc + cc[j]];
-            }
-            asm volatile("" ::"s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R), "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha),
-                         "s"(a.tail), "s"(a.epi), "s"(splitk), "s"(partial), "s"(a.Ch), "s"(a.Cl), "s"(a.cpl_ld), "s"(a.stats_out));
-            __builtin_amdgcn_sched_barrier(0);
-            SK_STAMP(2);
-#pragma unroll
-            for (int j = 0; j < NCH; j++) {
-                const int c = lane + 64 * j;
-                if (c * 8 >= nss * 128) continue;
-                const int off = wave * RB + (((c ^ wave) & CMASK) << 4);
-                const unsigned keep = cok[j] ? 0xffffffffu : 0u;   // chunks past the slice (clamped loads) become zeros
-                *reinterpret_cast<uint4*>(&Xh[off]) = make_uint4(vh[j].x & keep, vh[j].y & keep, vh[j].z & keep, vh[j].w & keep);
-                *reinterpret_cast<uint4*>(&Xl[off]) = make_uint4(vl[j].x & keep, vl[j].y & keep, vl[j].z & keep, vl[j].w & keep);
-            }
-        }
-    } else
     if (m0 + wave < p_m) {
         const int m = m0 + wave;
         const bool m_ok = true;
@@ -432,8 +380,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     __syncthreads();
     SK_STAMP(5);
     if (kq4 > 0) return;
-    const bool planes_out = a.Ch != nullptr;
-    if (!n_ok && !(PRO == 0 && a.stats_out)) return;   // a stats launch keeps its idle lanes: the 16-lane sums below read them as zeros
+    if (!n_ok) return;
     float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
 #pragma unroll
     for (int t = 1; t < KP; t++) {
@@ -449,15 +396,11 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         }
         return;
     }
-    float st_s[4] = {0.f, 0.f, 0.f, 0.f}, st_q[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         int m = m0 + q * 4 + reg;
         if (m >= p_m || !n_ok) continue;
         float v = acc[reg] * e_ws;
-        if constexpr (PRO == 0) {
-            if (a.stats_in) v = ln_rs[q * 4 + reg] * (v - ln_mu[q * 4 + reg] * e_wg) + e_wb;   // LayerNorm of the input rows, applied to the sums
-        }
         v += e_bias;
         int64_t co = (int64_t)m * a.cmap.ld + n;
         if (a.tail && n == p_n - 1) { a.tail[m] = v; continue; }
@@ -473,30 +416,8 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             case EPI_RESADD_ELU: v = elu1(e_r[reg] + v); break;
         }
         if (a.C) a.C[co] = v;
-        if (planes_out) {   // the value for the next launch's matrix cores: split once, here
-            unsigned hi, lo;
-            split2(v * e_cs, 0.f, hi, lo);
-            a.Ch[(int64_t)m * a.cpl_ld + n] = (uint16_t)(hi & 0xffffu);
-            a.Cl[(int64_t)m * a.cpl_ld + n] = (uint16_t)(lo & 0xffffu);
-        }
-        st_s[reg] = v; st_q[reg] = v * v;
         if constexpr (FIN)
             if (f_act[reg]) fu.fin->latents[(int64_t)m * fu.fin->lat_stride + (int64_t)f_step[reg] * fu.fin->ldim + n] = v;   // latentFrames = append(...)
-    }
-    if constexpr (PRO == 0) {
-        if (a.stats_out) {   // per-row partial sums over this wave's 16 columns (fixed order: DPP tree within the row of 16 lanes)
-            const int G = (p_n + 15) >> 4, g = blockIdx.x * CG + cg;
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                float s1 = st_s[reg], s2 = st_q[reg];
-                s1 += dpp_f32<0xB1>(s1); s2 += dpp_f32<0xB1>(s2);
-                s1 += dpp_f32<0x4E>(s1); s2 += dpp_f32<0x4E>(s2);
-                s1 += dpp_f32<0x141>(s1); s2 += dpp_f32<0x141>(s2);
-                s1 += dpp_f32<0x140>(s1); s2 += dpp_f32<0x140>(s2);
-                const int m = m0 + q * 4 + reg;
-                if ((lane & 15) == 0 && m < p_m && g < G) reinterpret_cast<float2*>(a.stats_out)[(int64_t)m * G + g] = make_float2(s1, s2);
-            }
-        }
     }
     if constexpr (FIN)
     if (cg == 0 && (lane & 15) == 0) {   // k_step_finish's bookkeeping (runtime_native_safetensors.go:176-192), one lane per row
@@ -529,10 +450,8 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 bool skinny_supported(const GemmArgs& a, int splitk) {
     if (splitk < 1) splitk = 1;
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    if (a.Ah && (a.K % 8 || !aligned16(a.Ah) || !aligned16(a.Al))) return false;
-    if ((a.stats_in && (a.stats_n > 64 || !a.wg || !a.wb)) || (a.Ch && !a.Cl)) return false;
     return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= (splitk > 1 && (a.w_bf16 || a.wt_i8) ? SK_KMAX2 : SK_KMAX) && (!a.wt_i8 || a.wscale) && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
-           (a.Ah || (a.amap.ld % 4 == 0 && aligned16(a.A))) && aligned16(a.W) && a.ldw % 8 == 0 && a.aop == AOP_NONE;
+           a.amap.ld % 4 == 0 && aligned16(a.A) && aligned16(a.W) && a.ldw % 8 == 0 && a.aop == AOP_NONE;
 }
 
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
@@ -593,33 +512,8 @@ static void launch_pro(const GemmArgs& a, const SkinnyFuse& fu, int splitk, floa
     else throw Error(PTTS_EINVAL, "ptts-hip: internal: K slice too deep for this variant of the step kernel");
 }
 
-// activations as split planes (GemmArgs::Ah): no fused prologue, same tile choices as above
-template <int WT, int NJ, int CG>
-static void launch_apl_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
-    dim3 grid((a.N + 16 * CG - 1) / (16 * CG), (a.M + 15) / 16, splitk);
-    if (g_skinny_ev[0])
-        hipExtLaunchKernelGGL((k_skinny<WT, false, 0, NJ, CG, false, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld, a.M, a.N,
-                              a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((k_skinny<WT, false, 0, NJ, CG, false, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial,
-                            (unsigned long long*)nullptr);
-}
-template <int WT>
-static void launch_apl(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
-    const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    const bool narrow = ((a.N + 63) / 64) * ((a.M + 15) / 16) * splitk < 128 && a.N > 16;
-    if (kslice <= 512) { if (narrow) launch_apl_cg<WT, 2, 1>(a, fu, splitk, partial, stream); else launch_apl_cg<WT, 2, 4>(a, fu, splitk, partial, stream); }
-    else if (kslice <= SK_KMAX) { if (narrow) launch_apl_cg<WT, 4, 1>(a, fu, splitk, partial, stream); else launch_apl_cg<WT, 4, 4>(a, fu, splitk, partial, stream); }
-    else if constexpr (WT != 0) launch_apl_cg<WT, 8, 2>(a, fu, splitk, partial, stream);
-    else throw Error(PTTS_EINVAL, "ptts-hip: internal: K slice too deep for this variant of the step kernel");
-}
-
 template <int WBF16>
 static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 grid, hipStream_t stream) {
-    if (a.Ah) {
-        if (fu.ln || fu.partial || fu.fin || !a.Al || a.K % 8) throw Error(PTTS_EINVAL, "ptts-hip: internal: split-plane activations take no fused prologue");
-        launch_apl<WBF16>(a, fu, splitk, partial, stream);
-        return;
-    }
     const int pro = (fu.ln ? PRO_LN : 0) | ((fu.ln && fu.ln_w) ? PRO_AFFINE : 0) | ((fu.ln && fu.scale) ? PRO_MOD : 0) | (fu.partial ? PRO_PARTIAL : 0);
     switch (pro) {
         case 0: launch_pro<WBF16, 0>(a, fu, splitk, partial, grid, stream); break;

@@ -43,7 +43,7 @@ class Cancelled(PttsError):
 
 class _Opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("weights", C.c_int32), ("kv", C.c_int32), ("max_batch", C.c_int32),
-                ("use_graph", C.c_int32), ("step_plan", C.c_int32), ("reserved", C.c_int32 * 10)]
+                ("use_graph", C.c_int32), ("reserved0", C.c_int32), ("reserved", C.c_int32 * 10)]
 
 
 class _Info(C.Structure):
@@ -266,11 +266,10 @@ class ModelInfo:
     frame_rate: float; encoder_frame_rate: float; n_params: int; arena_bytes: int; weights: int; kv: int
 
 
-def _opts(device=0, weights=WEIGHTS_F32, kv=KV_F32, max_batch=64, use_graph=False, step_plan=0) -> _Opts:
+def _opts(device=0, weights=WEIGHTS_F32, kv=KV_F32, max_batch=64, use_graph=False) -> _Opts:
     o = _Opts()
     lib().ptts_default_opts(C.byref(o))
     o.device, o.weights, o.kv, o.max_batch, o.use_graph = device, weights, kv, max_batch, 1 if use_graph else 0
-    o.step_plan = int(step_plan)
     return o
 
 

@@ -63,10 +63,7 @@ typedef struct ptts_opts {
                                 the GPU and there is no gap between steps; 1: the step is captured once into a hipGraph and
                                 replayed (one host call per step, ~8 us of idle GPU between replays: up to 3 % slower, but the
                                 launching thread needs a fraction of the CPU time) */
-    int32_t step_plan;       /* launch plan of the AR step, for A/B measurement (results agree to rounding): 0 default: every activation
-                                edge in f32, LayerNorms in the consumers' prologues; 1: the flow net's mlp0 -> mlp2 edge as split bf16
-                                planes; 2: planes on every edge, norm1 / out_norm as their own launch, norm2 folded into linear1's
-                                epilogue.  1 and 2 measured no faster (DESIGN.md "What the measurements changed") */
+    int32_t reserved0;       /* must be 0 (round 2's step_plan: the alternative launch plans were measurements, not options; they live in tools/probes/step_plans) */
     int32_t reserved[10];
 } ptts_opts;
 
@@ -336,12 +333,6 @@ int ptts_debug_step_stamps(ptts_batch* b, int32_t lsd_steps, uint64_t* out /* [c
                            int32_t cap_desc, int32_t* n_desc);
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
-/* the same product `reps` times on an operand re-copied on the device before every launch: runs whose bits differ from the first (a race check) */
-int ptts_debug_gemm_repeat(int32_t M, int32_t N, int32_t K, int32_t variant, int32_t epi, int32_t reps, int32_t mode /* 1: RoPE epilogue, 2: segmented output rows */,
-                           int32_t* bad_runs, float* maxdiff);
-/* clock stamps of block 0 of the persistent k_gemm4 over its first two tiles (tools/stamps_gemm4.py) */
-int ptts_debug_gemm4_stamps(int32_t M, int32_t N, int32_t K, uint64_t* out /* [2 tiles][64 steps][8 waves][8 stamps] */);
-
 /* audio.WritePCM16Samples on the device (internal/audio/wav_stream.go:43-54), without the byte packing */
 int ptts_op_pcm16(const float* samples, int64_t n, int16_t* out);
 
