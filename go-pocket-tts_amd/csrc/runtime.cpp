@@ -215,7 +215,7 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     const size_t f = sizeof(float);
     const int NA = d.ada_all.out;
     b->in_raw.ensure(B * d.ldim * f); b->in32.ensure(B * d.ldim * f);
-    b->x.ensure(B * d.d_model * f); b->xn.ensure(B * std::max(d.d_model, d.flow_dim) * f); b->x2.ensure(B * d.d_model * f);
+    b->x.ensure(B * d.d_model * f); b->xn.ensure(B * std::max(d.d_model, d.flow_dim) * f);
     b->qkv.ensure(B * 3 * d.d_model * f); b->attn.ensure(B * d.d_model * f);
     b->ff.ensure(B * d.ffn * f); b->last.ensure(B * d.d_model * f); b->eos.ensure(B * f);
     b->sy.ensure(B * d.flow_dim * f); b->ada.ensure(B * NA * f);
@@ -583,20 +583,22 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
     const int B = b.B, D = d.d_model, C = d.flow_dim, NA = d.ada_all.out;
     const bool kvb = m.opts.kv == PTTS_KV_BF16;
     float* x = b.x.as<float>();
-    float* x_alt = b.x2.as<float>();
     float* qkv = b.qkv.as<float>();
     float* attn = b.attn.as<float>();
     float* ff = b.ff.as<float>();
     if (!opened) step_gemm(m, mk(m, b.in32.as<float>(), flat(d.ldim), d.input_linear, x, flat(D), B));
+    // A split linear2 leaves [x + (sums_0 + bias)] in plane 0 and the raw sums of the other K slices in planes 1..S-1 (k_skinny, slice 0
+    // with GemmArgs::R set): the next consumer of the residual stream reads plane 0 as its rows and adds the others in order --
+    // with S = 2 (a full batch on bf16 weights) two row images per block instead of three (residual, two planes) plus the bias.
     Pending pend;
+    const float* xin = x;   // where the current residual rows are read from: x, or plane 0 while a split sum is pending
     for (int l = 0; l < d.n_layers; l++) {
         const auto& L = d.layers[l];
         {
             FusedIn in;
-            in.pend = pend; in.x_out = pend.partial ? x_alt : nullptr; in.norm = &L.n1; in.eps = L.n1.eps;
-            step_fused_linear(b, x, in, L.in_proj, qkv, 3 * D, B, EPI_NONE, nullptr, nullptr, 1.0f);
-            if (pend.partial) std::swap(x, x_alt);
-            pend = Pending{};
+            in.pend = pend; in.x_out = pend.partial ? x : nullptr; in.norm = &L.n1; in.eps = L.n1.eps;
+            step_fused_linear(b, xin, in, L.in_proj, qkv, 3 * D, B, EPI_NONE, nullptr, nullptr, 1.0f);
+            pend = Pending{}; xin = x;
         }
         AttnArgs a;
         a.k = b.kc(l); a.v = b.vc(l); a.kv_bf16 = kvb;
@@ -624,8 +626,11 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
             GemmArgs g2 = mk(m, ff, flat(d.ffn), L.l2, x, flat(D), B);
             const int S = pick_split(B, D, d.ffn, g2.w_bf16 != 0 || g2.wt_i8 != 0);
             if (S > 1 && skinny_supported(g2, S)) {
-                step_gemm(m, g2, SkinnyFuse{}, S, b.partial.as<float>());
-                pend.partial = b.partial.as<float>(); pend.splitk = S; pend.pstride = (int64_t)B * D; pend.bias = m.at<float>(L.l2.b);
+                float* planes = b.partial.as<float>();
+                g2.R = x;   // slice 0 stores x + (sums_0 + bias)
+                step_gemm(m, g2, SkinnyFuse{}, S, planes);
+                xin = planes;
+                pend.partial = planes + (size_t)B * D; pend.splitk = S - 1; pend.pstride = (int64_t)B * D; pend.bias = nullptr;
             } else {
                 g2.R = x; g2.epi = EPI_RESADD;
                 step_gemm(m, g2);
@@ -645,7 +650,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
     {
         FusedIn in;
         in.pend = pend; in.norm = &d.out_norm; in.eps = d.out_norm.eps;
-        GemmArgs g1 = mk(m, x, flat(D), d.cond_embed, sy, flat(C), B), g2 = mk(m, x, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B);
+        GemmArgs g1 = mk(m, xin, flat(D), d.cond_embed, sy, flat(C), B), g2 = mk(m, xin, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B);
         SkinnyFuse fu;
         fu.partial = pend.partial; fu.psplit = pend.splitk; fu.pstride = pend.pstride; fu.pbias = pend.bias;
         fu.ln = 1; fu.eps = in.eps; fu.ln_w = m.at<float>(d.out_norm.w); fu.ln_b = m.at<float>(d.out_norm.b);
@@ -653,19 +658,19 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         if (tail_fused) {
             in.y_out = last;
             if (d.cond_eos.wt != NONE) {   // one launch: columns 0..C-1 = cond_embed (SiLU epilogue), column C = out_eos (raw)
-                GemmArgs g = mk(m, x, flat(D), d.cond_eos, sy, flat(C), B);
+                GemmArgs g = mk(m, xin, flat(D), d.cond_eos, sy, flat(C), B);
                 g.epi = EPI_SILU; g.addvec = tc; g.tail = b.eos.as<float>();
                 SkinnyFuse f2 = fu;
                 f2.y_out = last;
                 step_gemm(m, g, f2);
             } else {
                 in.y_out = nullptr;
-                step_fused_linear(b, x, in, d.out_eos, b.eos.as<float>(), 1, B, EPI_NONE, nullptr, nullptr, 1.0f);
+                step_fused_linear(b, xin, in, d.out_eos, b.eos.as<float>(), 1, B, EPI_NONE, nullptr, nullptr, 1.0f);
                 in.y_out = last;
-                step_fused_linear(b, x, in, d.cond_embed, sy, C, B, EPI_SILU, tc, nullptr, 1.0f);
+                step_fused_linear(b, xin, in, d.cond_embed, sy, C, B, EPI_SILU, tc, nullptr, 1.0f);
             }
         } else {
-            LnArgs ln = mkln(m, x, flat(D), d.out_norm, last, D, B);
+            LnArgs ln = mkln(m, xin, flat(D), d.out_norm, last, D, B);
             ln.partial = pend.partial; ln.splitk = pend.splitk; ln.pstride = pend.pstride; ln.pbias = pend.bias;
             launch_layernorm(ln, s);
             step_gemm(m, mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B));

@@ -105,7 +105,7 @@ struct Batch {
     std::vector<const void*> pre_k_host, pre_v_host;
     std::vector<int32_t> pre_len_host;
     // step workspace
-    DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step, partial, x2;
+    DevBuf in_raw, in32, x, xn, qkv, attn, ff, last, eos, sy, ada, fx, fh, fh2, cur, noise_step, partial;
     DevBuf latents;          // [B][max_steps][ldim]
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;

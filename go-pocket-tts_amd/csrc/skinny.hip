@@ -58,7 +58,7 @@ union Frag8 {
 };
 
 // prologue variants (template parameter PRO)
-constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_TWO = 16;   // PRO_TWO (with PRO_PARTIAL): exactly two planes
+constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_ONE = 16;   // PRO_ONE (with PRO_PARTIAL): exactly one plane (the usual case: see below)
 
 // NJ: 256-column groups of the K slice per lane (2: K slice <= 512, 4: <= 1024, 8: <= 2048 -- halves the split-K planes the
 // consumer of a 4096-deep product has to re-read).
@@ -69,11 +69,19 @@ constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_TWO 
 // WT: how the weights are stored -- 0: f32, 1: bf16, 2: per-row-scaled int8 (offset-binary bytes; converted to bf16 in registers,
 // which is exact for [-127, 127]; the row scale is applied to the sums in the epilogue)
 template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false>
-__global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_m, int p_n, int p_k, int splitk, GemmArgs a, SkinnyFuse fu,
-                                                 float* partial, unsigned long long* stamps) {
-    // The seven leading scalars (copies of a.Wt, a.A, a.amap.ld, a.M, a.N, a.K, and the split) are what the weight and
-    // activation requests need.  They are built with -amdgpu-kernarg-preload-count: the dispatcher delivers them in SGPRs,
-    // so those requests leave before the first scalar-cache round trip for the argument block has returned.
+__global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_ms, int p_n, int p_k, const float* p_part, const float* p_lnw,
+                                                 const float* p_lnb, GemmArgs a, SkinnyFuse fu, float* partial, unsigned long long* stamps) {
+    // The nine leading scalars -- copies of a.Wt, a.A, a.amap.ld, a.M | split << 8, a.N, a.K, fu.partial, fu.ln_w, fu.ln_b: 14 dwords, all
+    // the user SGPRs a kernel can have preloaded (-amdgpu-kernarg-preload-count) -- arrive in registers with the dispatch, so every
+    // request on the critical path of the launch leaves before the first scalar-cache round trip for the argument block has
+    // returned (that block is cold on every dispatch: ~0.5-1 us).
+    // ORDER OF THE REQUESTS.  A wave's loads return in issue order (vmcnt counts down oldest first): whatever is requested after the
+    // weights cannot be consumed before the last weight byte of the wave has landed, and the weights are the long pole (32-128 KB per
+    // block from HBM: 2-5 us).  So the tile's rows, the first split-K plane and the LayerNorm vectors go out FIRST, the weights second:
+    // the whole prologue (sum, LayerNorm, hi/lo split, LDS image, the block's barrier) then runs while the weights stream, and each
+    // wave starts multiplying when its own weights arrive.  (Round 2 had the weights first: in-situ stamps showed every wave's
+    // prologue starting only when its weights were in, profiles/r3_step_stamps_weights_first.txt.)
+    const int p_m = p_ms & 0xff, splitk = p_ms >> 8;
     // stamps (tools/microbench.py only; null in the product): shader-clock ticks of wave 0 of every block at the phase boundaries
 #define SK_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
@@ -97,6 +105,43 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     const int ssq = (nss + KP - 1) / KP;       // super-steps per K part (<= NTW)
     const int ss_lo = kq4 * ssq;
 
+    // ---- activations: wave w stages row w of the tile; lane owns float4 columns lane + 64 j.  Requested first (see above): their
+    // addresses come from preloaded scalars alone ----
+    // Loads are unconditional within the row (a column >= klen replays column 0) and the value is masked afterwards.
+    // A wave whose row does not exist (batch not a multiple of 16: batch 1 has 15 of them) skips the prologue altogether: its
+    // LDS row feeds only output rows that are never stored, and the SIMD it shares is left to the waves with real rows.
+    const bool row_ok = m0 + wave < p_m;   // wave-uniform
+    const int64_t mrow = row_ok ? m0 + wave : 0;
+    float4 xr[NJ], ps[(PRO & PRO_PARTIAL) ? NJ : 1];
+    int kc[NJ];
+    bool kok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        const int k = (lane + 64 * j) * 4;
+        kok[j] = k < klen;
+        kc[j] = kok[j] ? k : 0;
+    }
+    if (row_ok) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) xr[j] = *reinterpret_cast<const float4*>(p_a + mrow * p_lda + k_begin + kc[j]);
+        if constexpr ((PRO & PRO_PARTIAL) != 0) {   // the first plane of the pending split-K sum (dense [psplit][M][K]: K is the row width here)
+#pragma unroll
+            for (int j = 0; j < NJ; j++) ps[j] = *reinterpret_cast<const float4*>(p_part + mrow * p_k + kc[j]);
+        }
+    }
+    // LayerNorm weight / bias of the lane's columns, with the rows (sharing one copy per block through LDS was measured: the extra
+    // barrier in front of the prologue cost more than the 120 KB of L1 hits it saved, profiles/r3_step_ab.txt)
+    float4 lwr[(PRO & PRO_AFFINE) ? NJ : 1], lbr[(PRO & PRO_AFFINE) ? NJ : 1];
+    if constexpr ((PRO & PRO_AFFINE) != 0) {
+        if (row_ok) {
+#pragma unroll
+            for (int j = 0; j < NJ; j++) { lwr[j] = *reinterpret_cast<const float4*>(p_lnw + kc[j]); lbr[j] = *reinterpret_cast<const float4*>(p_lnb + kc[j]); }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // The CU's vector-memory port serves its waves' requests in the order they were issued, across waves: without this barrier
+    // wave 15's rows queue behind the weights of waves 0..14 (120 KB), and the prologue of the block is as late as its last wave.
+    __builtin_amdgcn_s_barrier();
     // ---- weights: everything this wave will multiply is requested now ----
     // Fragment-ordered copy (model.cpp add_tiled, zero-padded to 16 columns x 128 k): one contiguous 1-KiB burst per
     // wave-instruction.  The loads are unconditional (a tile / super-step that does not exist re-reads block 0 and is never
@@ -117,70 +162,13 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             for (int s = 0; s < WV; s++) w[t][s] = src[s * 64];
         }
     }
-    __builtin_amdgcn_sched_barrier(0);   // keep the weight requests first: the scheduler otherwise sinks them below the first wait on x
-    // ---- epilogue operands: requested now by the waves that will store (K quarter 0), consumed after the K reduction ----
-    // (an element of R that aliases C is read and written by the same lane only)
-    float e_bias = 0.f, e_addv = 0.f, e_scl = 1.f, e_r[4] = {0.f, 0.f, 0.f, 0.f}, e_g[4] = {0.f, 0.f, 0.f, 0.f};
-    float e_ws = 1.0f;   // int8 weights: the scale of this lane's output column
-    if constexpr (WT == 2) { if (kq4 == 0) e_ws = a.wscale[n_ok ? n : 0]; }
-    if (kq4 == 0 && splitk <= 1) {
-        const int nc = n_ok ? n : 0;
-        if (a.bias) e_bias = a.bias[nc];
-        if (a.addvec) e_addv = a.addvec[(a.tail && nc == p_n - 1) ? 0 : nc];
-        if (a.scale) e_scl = a.scale[nc];
-        if (a.epi >= EPI_RESADD) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) e_r[reg] = a.R[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.cmap.ld + nc];
-        }
-        if (a.epi == EPI_GATE_RESADD) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) e_g[reg] = a.gate[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.ldg + nc];
-        }
-    }
-    // fused step bookkeeping: every storing wave reads its rows' counters now; the single lane per row that advances them does
-    // so after the block's last barrier, by which time these reads have returned (forced below)
-    int f_act[FIN ? 4 : 1] = {0}, f_step[FIN ? 4 : 1] = {0};
-    int f_cd[FIN ? 4 : 1] = {0}, f_fae[FIN ? 4 : 1] = {0}, f_max[FIN ? 4 : 1] = {0}, f_kv[FIN ? 4 : 1] = {0};   // the bookkeeping lane's operands,
-    float f_logit[FIN ? 4 : 1] = {0.f}, f_thr[FIN ? 4 : 1] = {0.f};                                             // requested now, used at the very end
-    if constexpr (FIN) {
-        if (kq4 == 0 && splitk <= 1) {
-            const StepState& fs = fu.fin->s;
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {
-                const int mm = min(m0 + q * 4 + reg, p_m - 1);
-                f_act[reg] = fs.active[mm];
-                f_step[reg] = fs.step[mm];
-                f_cd[reg] = fs.countdown[mm];
-                f_fae[reg] = fs.frames_after_eos[mm];
-                f_max[reg] = fs.max_steps[mm];
-                f_kv[reg] = fs.kv_len[mm];
-                f_logit[reg] = fu.fin->eos_logit[mm];
-                f_thr[reg] = fs.eos_threshold[mm];
-            }
-        }
-    }
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);   // rows, then weights, then everything that needs the argument block
     SK_STAMP(1);
-    // ---- activations: wave w stages row w of the tile; lane owns float4 columns lane + 64 j ----
-    // Loads are unconditional with clamped indices (a row >= M replays row 0, a column >= klen replays column 0) and the
-    // value is masked afterwards; the prologue variant is a template parameter so that a launch only holds the vectors
-    // it uses (16 waves per CU leave 128 VGPRs per lane).
-    // A wave whose row does not exist (batch not a multiple of 16: batch 1 has 15 of them) skips the prologue altogether: its
-    // LDS row feeds only output rows that are never stored, and the SIMD it shares is left to the waves with real rows.
-    if (m0 + wave < p_m) {
+    // ---- prologue: the rest of what the rows need (LayerNorm vectors, further planes) and the arithmetic; the prologue variant is a
+    // template parameter so that a launch only holds the vectors it uses (16 waves per CU leave 128 VGPRs per lane) ----
+    if (row_ok) {
         const int m = m0 + wave;
         const bool m_ok = true;
-        const int64_t mrow = m_ok ? m : 0;
-        float4 xr[NJ];
-        int kc[NJ];
-        bool kok[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int k = (lane + 64 * j) * 4;
-            kok[j] = k < klen;
-            kc[j] = kok[j] ? k : 0;
-            xr[j] = *reinterpret_cast<const float4*>(p_a + mrow * p_lda + k_begin + kc[j]);
-        }
         // Every other kernel argument is pulled into SGPRs here, in one batch of scalar loads.  The argument block of a fresh
         // dispatch is cold in the scalar cache and each miss is a round trip to memory (~0.5 us); left to itself the compiler
         // loads a field where it is first used, behind a branch on an earlier field, which chained five to six such round
@@ -189,21 +177,13 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         // fused-prologue variant was spilling 15 scalars to vector lanes (v_writelane / v_readlane on the critical path) to make room
         // for fields it never touches (the copies of Wt / A / lda / M / N / K arrive as leading arguments).
         asm volatile("" ::"s"(a.bias), "s"(a.addvec), "s"(a.C), "s"(a.cmap.ld), "s"(a.R), "s"(a.scale), "s"(a.gate), "s"(a.ldg), "s"(a.alpha),
-                     "s"(a.tail), "s"(a.epi), "s"(splitk), "s"(partial));
-        if constexpr ((PRO & PRO_PARTIAL) != 0) asm volatile("" ::"s"(fu.partial), "s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.x_out));
+                     "s"(a.tail), "s"(a.epi), "s"(partial));
+        if constexpr ((PRO & PRO_PARTIAL) != 0) asm volatile("" ::"s"(fu.psplit), "s"(fu.pstride), "s"(fu.pbias), "s"(fu.x_out));
         if constexpr ((PRO & PRO_LN) != 0) asm volatile("" ::"s"(fu.eps), "s"(fu.y_out));
-        if constexpr ((PRO & PRO_AFFINE) != 0) asm volatile("" ::"s"(fu.ln_w), "s"(fu.ln_b));
         if constexpr ((PRO & PRO_MOD) != 0) asm volatile("" ::"s"(fu.shift), "s"(fu.scale), "s"(fu.ldmod));
         if constexpr (FIN) asm volatile("" ::"s"(fu.fin));
-        float4 lw[(PRO & PRO_AFFINE) ? NJ : 1], lb[(PRO & PRO_AFFINE) ? NJ : 1], lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
+        float4 lc[(PRO & PRO_MOD) ? NJ : 1], lh[(PRO & PRO_MOD) ? NJ : 1];
         auto load_params = [&]() {
-            if constexpr ((PRO & PRO_AFFINE) != 0) {
-#pragma unroll
-                for (int j = 0; j < NJ; j++) {
-                    lw[j] = *reinterpret_cast<const float4*>(fu.ln_w + kc[j]);
-                    lb[j] = *reinterpret_cast<const float4*>(fu.ln_b + kc[j]);
-                }
-            }
             if constexpr ((PRO & PRO_MOD) != 0) {
 #pragma unroll
                 for (int j = 0; j < NJ; j++) {
@@ -212,34 +192,24 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
                 }
             }
         };
-        if constexpr ((PRO & PRO_PARTIAL) != 0) {   // x += sum_z partial[z] + bias; the partials are added in a fixed order
-            // the linear's output is summed first, then added to x, like the reference's y = W x + b; x += y
-            const float* pp = fu.partial + mrow * p_k;
-            float4 ps[NJ];
+        if constexpr ((PRO & PRO_PARTIAL) != 0) {   // rows += sum_z partial[z] (+ bias); the planes are added in a fixed order
+            // (the AR step hands over [x + (sums_0 + bias)] as the rows and the sums of the other K slices as planes: runtime.cpp step_core)
+            const float* pp = p_part + mrow * p_k;
+            if constexpr ((PRO & PRO_ONE) == 0) {
+                for (int z0 = 1; z0 < fu.psplit; z0 += 3) {   // three more slices per round trip
+                    float4 p[3][NJ];
 #pragma unroll
-            for (int j = 0; j < NJ; j++) ps[j] = *reinterpret_cast<const float4*>(pp + kc[j]);
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr ((PRO & PRO_TWO) != 0) {   // two planes (2048-deep slices of a 4096-deep product): exactly one more request per column group
-                float4 p1[NJ];
+                    for (int u = 0; u < 3; u++) {
+                        const int zz = min(z0 + u, fu.psplit - 1);
 #pragma unroll
-                for (int j = 0; j < NJ; j++) p1[j] = *reinterpret_cast<const float4*>(pp + (int64_t)fu.pstride + kc[j]);
+                        for (int j = 0; j < NJ; j++) p[u][j] = *reinterpret_cast<const float4*>(pp + (int64_t)zz * fu.pstride + kc[j]);
+                    }
 #pragma unroll
-                for (int j = 0; j < NJ; j++) { ps[j].x += p1[j].x; ps[j].y += p1[j].y; ps[j].z += p1[j].z; ps[j].w += p1[j].w; }
-                __builtin_amdgcn_sched_barrier(0);   // the LayerNorm vectors are requested after these have been consumed (register budget)
-            } else
-            for (int z0 = 1; z0 < fu.psplit; z0 += 3) {   // three more slices per round trip
-                float4 p[3][NJ];
+                    for (int u = 0; u < 3; u++) {
+                        if (z0 + u < fu.psplit) {
 #pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    const int zz = min(z0 + u, fu.psplit - 1);
-#pragma unroll
-                    for (int j = 0; j < NJ; j++) p[u][j] = *reinterpret_cast<const float4*>(pp + (int64_t)zz * fu.pstride + kc[j]);
-                }
-#pragma unroll
-                for (int u = 0; u < 3; u++) {
-                    if (z0 + u < fu.psplit) {
-#pragma unroll
-                        for (int j = 0; j < NJ; j++) { ps[j].x += p[u][j].x; ps[j].y += p[u][j].y; ps[j].z += p[u][j].z; ps[j].w += p[u][j].w; }
+                            for (int j = 0; j < NJ; j++) { ps[j].x += p[u][j].x; ps[j].y += p[u][j].y; ps[j].z += p[u][j].z; ps[j].w += p[u][j].w; }
+                        }
                     }
                 }
             }
@@ -293,8 +263,9 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             for (int j = 0; j < NJ; j++) {
                 f32x2 oa = (f32x2{xr[j].x, xr[j].y} - m2) * is2, ob = (f32x2{xr[j].z, xr[j].w} - m2) * is2;
                 if constexpr ((PRO & PRO_AFFINE) != 0) {
-                    oa = oa * f32x2{lw[j].x, lw[j].y} + f32x2{lb[j].x, lb[j].y};
-                    ob = ob * f32x2{lw[j].z, lw[j].w} + f32x2{lb[j].z, lb[j].w};
+                    const float4 lw = lwr[j], lb = lbr[j];
+                    oa = oa * f32x2{lw.x, lw.y} + f32x2{lb.x, lb.y};
+                    ob = ob * f32x2{lw.z, lw.w} + f32x2{lb.z, lb.w};
                 }
                 if constexpr ((PRO & PRO_MOD) != 0) {
                     const f32x2 one = {1.0f, 1.0f};
@@ -322,6 +293,52 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     }
     __syncthreads();
     SK_STAMP(3);
+    // ---- epilogue operands: requested by the waves that will store (K quarter 0) now that the image is staged -- behind the weights in
+    // the wave's queue, so that the prologue above never waits for anything younger than the rows (these loads sit under branches:
+    // the compiler's wait counts across them are conservative) -- and consumed after the K reduction ----
+    // (an element of R that aliases C is read and written by the same lane only)
+    float e_bias = 0.f, e_addv = 0.f, e_scl = 1.f, e_r[4] = {0.f, 0.f, 0.f, 0.f}, e_g[4] = {0.f, 0.f, 0.f, 0.f};
+    float e_ws = 1.0f;   // int8 weights: the scale of this lane's output column
+    if constexpr (WT == 2) { if (kq4 == 0) e_ws = a.wscale[n_ok ? n : 0]; }
+    // split launches (raw sums per K slice): slice 0 carries residual + bias when a.R is set, so that the consumer of the planes
+    // reads [R + (sums_0 + bias)] + sums_1 ... -- one row image fewer than residual, planes and bias separately
+    const bool epi_ops = kq4 == 0 && (splitk <= 1 || (z == 0 && a.R != nullptr));
+    if (epi_ops) {
+        const int nc = n_ok ? n : 0;
+        if (a.bias) e_bias = a.bias[nc];
+        if (a.addvec) e_addv = a.addvec[(a.tail && nc == p_n - 1) ? 0 : nc];
+        if (a.scale) e_scl = a.scale[nc];
+        if (a.epi >= EPI_RESADD || splitk > 1) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) e_r[reg] = a.R[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.cmap.ld + nc];
+        }
+        if (a.epi == EPI_GATE_RESADD) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) e_g[reg] = a.gate[(int64_t)min(m0 + q * 4 + reg, p_m - 1) * a.ldg + nc];
+        }
+    }
+    // fused step bookkeeping: every storing wave reads its rows' counters now; the single lane per row that advances them does
+    // so after the block's last barrier, by which time these reads have returned (forced below)
+    int f_act[FIN ? 4 : 1] = {0}, f_step[FIN ? 4 : 1] = {0};
+    int f_cd[FIN ? 4 : 1] = {0}, f_fae[FIN ? 4 : 1] = {0}, f_max[FIN ? 4 : 1] = {0}, f_kv[FIN ? 4 : 1] = {0};   // the bookkeeping lane's operands,
+    float f_logit[FIN ? 4 : 1] = {0.f}, f_thr[FIN ? 4 : 1] = {0.f};                                             // requested now, used at the very end
+    if constexpr (FIN) {
+        if (kq4 == 0 && splitk <= 1) {
+            const StepState& fs = fu.fin->s;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+                const int mm = min(m0 + q * 4 + reg, p_m - 1);
+                f_act[reg] = fs.active[mm];
+                f_step[reg] = fs.step[mm];
+                f_cd[reg] = fs.countdown[mm];
+                f_fae[reg] = fs.frames_after_eos[mm];
+                f_max[reg] = fs.max_steps[mm];
+                f_kv[reg] = fs.kv_len[mm];
+                f_logit[reg] = fu.fin->eos_logit[mm];
+                f_thr[reg] = fs.eos_threshold[mm];
+            }
+        }
+    }
 
     f32x4 acc_h = {0.f, 0.f, 0.f, 0.f}, acc_l = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15;
@@ -369,13 +386,13 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             }
         }
     }
-    // ---- sum the four K quarters of each column group (fixed order), reusing the activation image ----
+    // ---- sum the K parts of each column group (fixed order) through a region of its own: no wave has to wait for the others to
+    // have finished reading the activation image before it parks its sums ----
     if (STAMP) { if (acc_h[0] == 1.2345e-30f) SK_STAMP(6); }   // (stamp build) make stamp 4 wait for the MFMA results
     SK_STAMP(4);
-    __syncthreads();
-    float4* red = reinterpret_cast<float4*>(Xh);   // [kq4][cg][lane]
+    __shared__ float4 red[(KP - 1) * CG * 64];   // [kq4 - 1][cg][lane]
     const f32x4 accv = acc_h + acc_l;
-    if (kq4 > 0) red[(kq4 * CG + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
+    if (kq4 > 0) red[((kq4 - 1) * CG + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
     if constexpr (FIN) asm volatile("" ::"v"(f_act[0]), "v"(f_act[1]), "v"(f_act[2]), "v"(f_act[3]), "v"(f_step[0]), "v"(f_step[1]), "v"(f_step[2]), "v"(f_step[3]));
     __syncthreads();
     SK_STAMP(5);
@@ -384,40 +401,72 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
 #pragma unroll
     for (int t = 1; t < KP; t++) {
-        float4 p = red[(t * CG + cg) * 64 + lane];
+        float4 p = red[((t - 1) * CG + cg) * 64 + lane];
         acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
     }
+    if (STAMP) { if (acc[0] == 1.2345e-30f) SK_STAMP(6); SK_STAMP(1); }   // (stamp build) sums final; slots 1 / 2 are rewritten here: the epilogue's own phases
     // D layout of 16x16x32: column (n) = lane & 15, row (m) = (lane >> 4) * 4 + reg
     if (splitk > 1) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             int m = m0 + q * 4 + reg;
-            if (m < p_m && n_ok) partial[((int64_t)z * p_m + m) * p_n + n] = acc[reg] * e_ws;
+            float v = acc[reg] * e_ws;
+            if (z == 0 && a.R) v = e_r[reg] + (v + e_bias);
+            if (m < p_m && n_ok) partial[((int64_t)z * p_m + m) * p_n + n] = v;
         }
         return;
     }
+    // One pass over the epilogue form for the lane's four values (not the form re-decided per value: the unrolled switch was 1100
+    // instructions of branches that every storing wave walked through cold -- in-situ stamps put 1.7-2.2 us between "sums final" and
+    // "stores issued" in EVERY variant, two fifths of a small launch, profiles/r3_step_stamps_epilogue.txt).
+    float v[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) v[reg] = acc[reg] * e_ws + e_bias;
+    const bool to_tail = a.tail != nullptr && n == p_n - 1;   // the out_eos column rides as the last column of cond_embed
+    switch (a.epi) {
+        case EPI_NONE: break;
+        case EPI_GELU:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : gelu1(v[reg]);
+            break;
+        case EPI_SILU:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : silu1(e_addv + v[reg]);
+            break;
+        case EPI_ELU:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : elu1(v[reg]);
+            break;
+        case EPI_RESADD:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : e_r[reg] + v[reg];
+            break;
+        case EPI_SCALE_RESADD:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : e_r[reg] + e_scl * v[reg];
+            break;
+        case EPI_GATE_RESADD:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : e_r[reg] + e_g[reg] * v[reg];
+            break;
+        case EPI_AXPY:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : e_r[reg] + a.alpha * v[reg];
+            break;
+        case EPI_RESADD_ELU:
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : elu1(e_r[reg] + v[reg]);
+            break;
+    }
+    float* const cbase = to_tail ? a.tail : a.C;
+    const int64_t cld = to_tail ? 1 : a.cmap.ld;
+    const int ccol = to_tail ? 0 : n;
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
-        int m = m0 + q * 4 + reg;
-        if (m >= p_m || !n_ok) continue;
-        float v = acc[reg] * e_ws;
-        v += e_bias;
-        int64_t co = (int64_t)m * a.cmap.ld + n;
-        if (a.tail && n == p_n - 1) { a.tail[m] = v; continue; }
-        switch (a.epi) {
-            case EPI_NONE: break;
-            case EPI_GELU: v = gelu1(v); break;
-            case EPI_SILU: v = silu1(e_addv + v); break;
-            case EPI_ELU: v = elu1(v); break;
-            case EPI_RESADD: v = e_r[reg] + v; break;
-            case EPI_SCALE_RESADD: v = e_r[reg] + e_scl * v; break;
-            case EPI_GATE_RESADD: v = e_r[reg] + e_g[reg] * v; break;
-            case EPI_AXPY: v = e_r[reg] + a.alpha * v; break;
-            case EPI_RESADD_ELU: v = elu1(e_r[reg] + v); break;
-        }
-        if (a.C) a.C[co] = v;
+        const int m = m0 + q * 4 + reg;
+        if (m < p_m && cbase) cbase[(int64_t)m * cld + ccol] = v[reg];
         if constexpr (FIN)
-            if (f_act[reg]) fu.fin->latents[(int64_t)m * fu.fin->lat_stride + (int64_t)f_step[reg] * fu.fin->ldim + n] = v;   // latentFrames = append(...)
+            if (m < p_m && !to_tail && f_act[reg]) fu.fin->latents[(int64_t)m * fu.fin->lat_stride + (int64_t)f_step[reg] * fu.fin->ldim + n] = v[reg];   // latentFrames = append(...)
     }
     if constexpr (FIN)
     if (cg == 0 && (lane & 15) == 0) {   // k_step_finish's bookkeeping (runtime_native_safetensors.go:176-192), one lane per row
@@ -443,7 +492,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             if (done) { fs.active[m] = 0; atomicSub(fs.n_active, 1); }
         }
     }
-    if (STAMP) { __builtin_amdgcn_s_waitcnt(0); SK_STAMP(6); }
+    if (STAMP) { SK_STAMP(2); __builtin_amdgcn_s_waitcnt(0); SK_STAMP(6); }   // stores issued; stores acknowledged
 #undef SK_STAMP
 }
 
@@ -472,8 +521,8 @@ static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
         if (fu.fin) {   // the flow net's final layer with the step's bookkeeping in its epilogue (one column block: grid.x == 1)
             if (g_skinny_ev[0])
                 hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld,
-                                      a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
-            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial,
+                                      a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
+            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
                                     (unsigned long long*)nullptr);
             return;
         }
@@ -481,18 +530,18 @@ static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
     if (SkinnyStampLog* lg = g_skinny_stamp_log) {
         const size_t blocks = (size_t)grid.x * grid.y * grid.z;
         if (lg->used_blocks + blocks <= lg->cap_blocks) {
-            hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial,
+            hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
                                lg->base + 8 * lg->used_blocks);
             lg->used_blocks += blocks;
             lg->desc.push_back(SkinnyStampLog::Desc{a.M, a.N, a.K, PRO, NJ, CG, (int32_t)blocks, splitk});
             return;
         }
     }
-    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, g_skinny_stamps);
+    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, g_skinny_stamps);
     else if (g_skinny_ev[0])   // hipExtLaunchKernel stamps the dispatch itself: the same interval rocprofv3 reports for the kernel
-        hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld, a.M, a.N,
-                              a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M, a.N, a.K, splitk, a, fu, partial, (unsigned long long*)nullptr);
+        hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N,
+                              a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
 }
 
 template <int WBF16, int PRO, int NJ>
@@ -519,7 +568,7 @@ static void launch_w(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float*
         case 0: launch_pro<WBF16, 0>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN | PRO_AFFINE: launch_pro<WBF16, PRO_LN | PRO_AFFINE>(a, fu, splitk, partial, grid, stream); break;
         case PRO_LN | PRO_AFFINE | PRO_PARTIAL:
-            if (fu.psplit == 2) launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL | PRO_TWO>(a, fu, splitk, partial, grid, stream);
+            if (fu.psplit == 1) launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL | PRO_ONE>(a, fu, splitk, partial, grid, stream);
             else launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_PARTIAL>(a, fu, splitk, partial, grid, stream);
             break;
         case PRO_LN | PRO_AFFINE | PRO_MOD: launch_pro<WBF16, PRO_LN | PRO_AFFINE | PRO_MOD>(a, fu, splitk, partial, grid, stream); break;

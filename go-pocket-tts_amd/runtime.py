@@ -19,7 +19,7 @@ from typing import Callable, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libptts_hip.so")
+LIB_PATH = os.environ.get("PTTS_LIB_PATH") or os.path.join(_HERE, "libptts_hip.so")   # PTTS_LIB_PATH: A/B of two builds on one box (tools/gpu_r3.sh)
 
 PTTS_OK, PTTS_EINVAL, PTTS_EIO, PTTS_EFORMAT, PTTS_ENODEVICE, PTTS_ECANCELLED, PTTS_ENOMEM = range(7)
 WEIGHTS_F32, WEIGHTS_BF16, WEIGHTS_INT8 = 0, 1, 2

@@ -232,3 +232,49 @@ def test_config4_shape_at_full_size(pkg, tmp_path):
     parity("configs[4] full size: first three latent frames vs oracle(W^)", out[0].latents[:3], ref["latents"], (4e-3, 5e-2), rel_floor=1e-1)
     om_q.close()
     gm.close()
+
+
+def test_config4_streaming_at_full_size_encoder_left_out(pkg, tmp_path):
+    """BASELINE.json configs[4]'s STREAMING leg at the reference's tensor shapes, as far as it exists without the Mimi encoder (its
+    latents are an input; ErrMimiEncoderNotImplemented in the reference, mimi.go:14,791-794): four 188-frame chunks of one long text
+    (60.16 s) in one batched call on int8 step weights + bf16 KV under graph replay, a cloned-voice embedding, PCM16 egress, and
+    `pcm_callback` announcing 12-frame ranges while the AR loop is still running (the /tts/stream path at frame granularity,
+    server.go:354-396).  Every sample is handed over exactly once and in order, each chunk's ranges concatenate to exactly what the
+    call returns, the latents are the non-streamed call's bit for bit (streaming only changes WHEN frames are decoded) and the audio
+    equals the non-streamed audio to the +/-2 LSB a differently tiled decode is allowed (tests/test_gpu_model.py, same bound)."""
+    synth = pkg.synth
+    cfg = dataclasses.replace(synth.SynthConfig.full(), speaker_proj=True)
+    tens = synth.make_checkpoint(cfg, seed=77)
+    path = str(tmp_path / "full_sp.safetensors")
+    synth.write_safetensors(path, tens, dtype="BF16")
+    gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_INT8, kv=1, max_batch=8, use_graph=True)
+    rng = np.random.default_rng(8)
+    emb = gm.speaker_project((rng.standard_normal((125, 512)) * 0.3).astype(np.float32))
+    voice = pkg.VoiceEmbedding(emb, (1,) + emb.shape)
+    toks = [p.tolist() for p in synth.make_prompts(4, 40, cfg.n_bins, seed=3)]
+    frames, per = 188, 12
+    whole = gm.generate_batch(toks, [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=frames, voice_embedding=voice,
+                                                                 want_latents=True, pcm16=True)] * 4)
+    got_chunks = [[] for _ in toks]
+    order = []
+
+    def mk(i):
+        def cb(off, x):
+            got_chunks[i].append((off, x.copy()))
+            order.append(i)
+        return cb
+
+    cfgs = [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=frames, voice_embedding=voice, want_latents=True, pcm16=True,
+                                      pcm_callback=mk(i), stream_frames=per) for i in range(4)]
+    got = gm.generate_batch(toks, cfgs)
+    for i in range(4):
+        assert got[i].n_frames == frames and got[i].pcm.dtype == np.int16 and got[i].pcm.size == frames * 1920
+        assert np.array_equal(got[i].latents, whole[i].latents)
+        offs = [o for o, _ in got_chunks[i]]
+        sizes = [c.size for _, c in got_chunks[i]]
+        assert offs[0] == 0 and all(offs[k + 1] == offs[k] + sizes[k] for k in range(len(offs) - 1)) and offs[-1] + sizes[-1] == frames * 1920
+        assert len(got_chunks[i]) == (frames + per - 1) // per and all(s % 1920 == 0 and s <= per * 1920 for s in sizes)
+        assert np.array_equal(np.concatenate([c for _, c in got_chunks[i]]), got[i].pcm)
+        assert np.abs(got[i].pcm.astype(np.int32) - whole[i].pcm.astype(np.int32)).max() <= 2
+    assert len(order) == 4 * ((frames + per - 1) // per)
+    gm.close()

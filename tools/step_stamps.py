@@ -34,7 +34,7 @@ n = C.c_int32(0)
 L.ptts_debug_step_stamps.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
 rc = L.ptts_debug_step_stamps(b.h, 1, buf.ctypes.data, cap, desc.ctypes.data, 128, C.byref(n))
 assert rc == 0, L.ptts_last_error().decode()
-names = ["w issued", "x+LN", "staged", "mfma", "k-red", "stored"]
+names = ["sums", "st.issued", "staged", "mfma", "k-red", "stored"]   # slots 1..6; 1 and 2 are stamped in the epilogue (sums final, stores issued)
 off = 0
 t_first = None
 print(f"{'launch':28s} {'blocks':>6s} {'start us':>8s} " + " ".join(f"{x:>9s}" for x in names) + "   (p50 ticks since block entry; last column p100 stored)")
