@@ -357,7 +357,9 @@ int ptts_dispatcher_create(ptts_model* const* models, int32_t n_models, const pt
             if (!models[i] || !models[i]->m) throw Error(PTTS_EINVAL, "dispatcher: nil model");
             ms.push_back(models[i]->m);
         }
-        *out = new ptts_dispatcher{dispatcher_create(ms.data(), n_models, nullptr, nullptr, 0, o ? o->max_batch : 0, o ? o->window_us : 2000, o ? o->queue_cap : 0)};
+        DispatchCont dc;
+        if (o) { dc.on = o->continuous; dc.kv_capacity = o->cont_kv_capacity; dc.max_steps = o->cont_max_steps; dc.steps_per_group = o->cont_steps_per_group; }
+        *out = new ptts_dispatcher{dispatcher_create(ms.data(), n_models, nullptr, nullptr, 0, o ? o->max_batch : 0, o ? o->window_us : 2000, o ? o->queue_cap : 0, &dc)};
     });
 }
 

@@ -1,0 +1,525 @@
+// continuous.cpp -- continuous batching for the serving path.
+//
+// The reference admits `workers` Synthesize calls at a time (internal/server/server.go:398-421) and runs each call's chunks one after
+// the other (internal/tts/service.go:138-153); utterances end where their EOS logit says (runtime_native_safetensors.go:178-190), so
+// their lengths differ.  The batch-at-a-time dispatcher (dispatcher.cpp) forms a batch, steps it until its LAST utterance has ended
+// and only then forms the next: finished slots idle for the rest of the batch, waiting callers wait for all of it.  Here one long-lived
+// batch of `slots` utterance states is stepped for as long as there is work:
+//   * between groups of AR steps the slots' counters are read back (one 1-KB copy); a slot whose utterance has ended hands its latent
+//     frames to the Mimi decoder (second stream, beside the following steps) and is free again;
+//   * waiting requests move into free slots at once: their prompts are prefilled as one ragged launch sequence over the new slots only
+//     (batch_prompt with empty segments for the running ones), their bookkeeping is (re)initialised by one small kernel;
+//   * every caller's audio equals what the same request returns on its own (same kernels, same per-slot arithmetic: rows of a batch
+//     never mix) -- tests/test_gpu_continuous.py.
+// Nothing in the loop waits for the GPU to run dry: the counters of group g are read (asynchronously, into page-locked memory) while
+// group g + 1 is already queued, admissions and decodes are queued behind the group in flight, per-slot device state is written slot
+// by slot by one small kernel (never as whole arrays: the other slots are live), and small uploads go through two page-locked arenas
+// used in turn.  Prefills and decodes interrupt / compete with the step chain, so both are batched: newcomers are admitted every
+// few groups (or at once into an empty engine), finished utterances are decoded a handful at a time.
+// The engine has a fixed geometry (slots, KV capacity, step budget); requests that do not fit it or need per-step host work (step /
+// PCM callbacks, lsd_steps > 1) are left to the batch-at-a-time path.
+#include <algorithm>
+#include <cmath>
+#include <deque>
+
+#include "runtime.h"
+
+namespace ptts {
+
+namespace {
+constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
+}
+
+struct ContEngine {
+    Model& m;
+    std::unique_ptr<Batch> b;
+    int B = 0, cap = 0, max_steps = 0;
+    struct Slot {
+        bool busy = false;        // holds an utterance that is still generating
+        const ptts_request* req = nullptr;
+        ptts_result* res = nullptr;
+        void* tag = nullptr;
+        int ms = 0;               // step budget
+        int base_kv = 0;          // cache length after the prefill: the slot's device kv_len is base_kv + n_frames
+        uint64_t admit_seq = 0;   // groups launched before the slot was filled: read-backs of those groups predate it
+        bool finished = false;    // (transient, inside one read-back) ended: its frames are copied out and the slot is free again
+        int nf = 0, eos = -1;     // ... with this many frames / this EOS step
+        uint64_t fin_seq = 0;
+        int nf_seen = 0; uint64_t seen_seq = 0;   // last read-back that covered the slot: frames then, group then
+        bool joining = false;     // its prompt is still being prefilled on the I/O stream: not stepping yet
+    };
+    std::vector<Slot> slots;
+    int n_gen = 0;
+    struct Pending {              // a group of finished utterances whose audio is being decoded on the second stream
+        hipEvent_t done = nullptr;
+        std::vector<void*> tags;
+        std::vector<ptts_result*> res;
+    };
+    std::deque<Pending> decoding;
+    // ended utterances whose frames wait (in a staging row of their own, so that the slot is free at once) for a decode worth launching
+    struct Staged { const ptts_request* req; ptts_result* res; void* tag; int nf, eos, row; uint64_t seq; };
+    std::vector<Staged> staged;
+    DevBuf stage;                         // [2 B rows][max_steps][ldim]
+    std::vector<int> stage_free;
+    // newcomers whose voice ingestion and prefill are running on the I/O stream; they start stepping once that is done
+    struct Joining { hipEvent_t ready = nullptr; std::vector<int> slots; int ring = 0; };
+    std::deque<Joining> joining;
+    hipStream_t io = nullptr;
+    DevBuf adm_dev[4];
+    int adm_turn = 0;
+    std::vector<hipEvent_t> free_events;
+    // read-backs: [5 B] active | step | countdown | n_frames | eos_step as they sit in the state block, two in rotation
+    struct Snap { int32_t* host = nullptr; hipEvent_t ready = nullptr; uint64_t seq = 0; bool pending = false; };
+    Snap snaps[2];
+    uint64_t seq = 0;                     // groups of steps launched so far
+    int group_steps = 1;
+    uint64_t last_admit_seq = 0;
+    UploadArena arenas[2];
+    hipEvent_t arena_free[2] = {nullptr, nullptr};
+    int arena_turn = 0;
+    hipEvent_t ev_steps = nullptr, ev_gather = nullptr;
+    std::unique_lock<std::mutex> hold;    // the model's mutex, held while the engine has work in flight
+    bool use_graph = false;
+    int64_t admissions = 0, admitted = 0;
+
+    explicit ContEngine(Model& model) : m(model) {}
+    ~ContEngine() {
+        (void)hipStreamSynchronize(m.stream);
+        (void)hipStreamSynchronize(m.stream2);
+        if (io) { (void)hipStreamSynchronize(io); (void)hipStreamDestroy(io); }
+        for (auto& j : joining) if (j.ready) (void)hipEventDestroy(j.ready);
+        for (auto& p : decoding) if (p.done) (void)hipEventDestroy(p.done);
+        for (hipEvent_t e : free_events) (void)hipEventDestroy(e);
+        if (ev_steps) (void)hipEventDestroy(ev_steps);
+        if (ev_gather) (void)hipEventDestroy(ev_gather);
+        for (Snap& sn : snaps) { if (sn.host) (void)hipHostFree(sn.host); if (sn.ready) (void)hipEventDestroy(sn.ready); }
+        for (int i = 0; i < 2; i++) { if (arenas[i].base) (void)hipHostFree(arenas[i].base); if (arena_free[i]) (void)hipEventDestroy(arena_free[i]); }
+        b.reset();
+        if (hold.owns_lock()) hold.unlock();
+    }
+    int free_slots() const { int n = 0; for (const Slot& s : slots) n += !s.busy; return n; }
+    int n_finished() const { return (int)staged.size(); }
+    int busy() const { return n_gen + n_finished() + (int)decoding.size() + (int)joining.size() + (snaps[0].pending || snaps[1].pending ? 1 : 0); }
+    hipEvent_t event() {
+        if (!free_events.empty()) { hipEvent_t e = free_events.back(); free_events.pop_back(); return e; }
+        hipEvent_t e;
+        PTTS_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    }
+    void lock_model() { if (!hold.owns_lock()) { hold = std::unique_lock<std::mutex>(m.mu); m.use_device(); } }
+    void unlock_if_idle() { if (busy() == 0 && hold.owns_lock()) hold.unlock(); }
+};
+
+ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
+    if (slots <= 0 || slots > 64) throw Error(PTTS_EINVAL, "continuous batch: 1..64 slots (the AR step kernels take up to 64 rows)");
+    kv_cap = (std::max(kv_cap, 64) + 63) / 64 * 64;
+    std::unique_ptr<ContEngine> e(new ContEngine(m));
+    std::lock_guard<std::mutex> lock(m.mu);
+    m.use_device();
+    e->B = slots; e->cap = kv_cap; e->max_steps = std::max(1, max_steps);
+    e->b.reset(batch_new(m, slots, kv_cap, e->max_steps));
+    Batch& b = *e->b;
+    // every slot starts free: nothing is live until a request moves in
+    launch_fill_i32(b.st.active, 0, slots, m.stream);
+    launch_fill_i32(b.st.n_active, 0, 1, m.stream);
+    // the noise rows exist from the start (zeros for greedy requests): a captured step reads them whatever the slot's temperature
+    const size_t nz = (size_t)slots * b.max_steps * m.d.ldim * sizeof(float);
+    b.noise.ensure(nz);
+    PTTS_HIP(hipMemsetAsync(b.noise.p, 0, nz, m.stream));
+    b.has_noise = true;
+    e->slots.assign((size_t)slots, ContEngine::Slot{});
+    for (ContEngine::Snap& sn : e->snaps) {
+        PTTS_HIP(hipHostMalloc((void**)&sn.host, sizeof(int32_t) * 5 * (size_t)slots, hipHostMallocDefault));
+        PTTS_HIP(hipEventCreateWithFlags(&sn.ready, hipEventDisableTiming));
+    }
+    for (int i = 0; i < 2; i++) PTTS_HIP(hipEventCreateWithFlags(&e->arena_free[i], hipEventDisableTiming));
+    b.slot_local = true;
+    PTTS_HIP(hipStreamCreateWithFlags(&e->io, hipStreamNonBlocking));
+    b.io_stream = e->io;
+    for (DevBuf& db : e->adm_dev) db.ensure((size_t)slots * sizeof(SlotAdmit));
+    e->stage.ensure((size_t)2 * slots * b.max_steps * m.d.ldim * sizeof(float));
+    for (int i = 2 * slots - 1; i >= 0; i--) e->stage_free.push_back(i);
+    PTTS_HIP(hipEventCreateWithFlags(&e->ev_steps, hipEventDisableTiming));
+    PTTS_HIP(hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming));
+    m.tcomb_for(1);
+    // the decoder's workspaces at their largest, so that a later, bigger group of finished utterances never reallocates a buffer an
+    // earlier group's kernels are still using
+    { MimiWs w; mimi_setup(m, w, 1, kFramesPerDecode + kFramesPerDecode / 8); }
+    m.work(7, (size_t)(kFramesPerDecode + kFramesPerDecode / 8) * m.d.samples_per_frame * sizeof(float));
+    m.work(8, (size_t)(kFramesPerDecode + kFramesPerDecode / 8) * m.d.samples_per_frame * sizeof(int16_t));
+    m.work(13, (size_t)(kFramesPerDecode + kFramesPerDecode / 8) * m.d.ldim * sizeof(float));
+    static const int env_graph = [] { const char* g = getenv("PTTS_GRAPH"); return g ? atoi(g) : -1; }();
+    e->use_graph = env_graph >= 0 ? env_graph != 0 : m.opts.use_graph != 0;
+    PTTS_HIP(hipStreamSynchronize(m.stream));
+    return e.release();
+}
+
+void cont_destroy(ContEngine* e) { delete e; }
+int cont_free_slots(const ContEngine& e) { return e.free_slots(); }
+int cont_busy(const ContEngine& e) { return e.busy(); }
+void cont_counts(const ContEngine& e, int64_t* admissions, int64_t* admitted) { *admissions = e.admissions; *admitted = e.admitted; }
+
+bool cont_accepts(const ContEngine& e, const ptts_request& r) {
+    if (r.step_callback || r.pcm_callback || r.lsd_steps > 1) return false;
+    const int ms = resolve_max_steps(r);
+    const int tp = (int)r.n_tokens + (r.voice_embedding ? (int)r.voice_frames : 0);
+    const int off = r.voice ? reinterpret_cast<const Voice*>(r.voice)->offset : (r.voice_caches ? (int)r.voice_offsets[0] : 0);
+    return ms <= e.max_steps && off + tp + ms <= e.cap && ms <= ROPE_SEQ / e.m.d.up_stride;
+}
+
+// n waiting requests move into free slots (n <= cont_free_slots): voice state, prompt prefill, bookkeeping, noise rows
+void cont_admit(ContEngine& e, const ptts_request* const* reqs, ptts_result* const* results, void* const* tags, int n) {
+    if (n <= 0) return;
+    Model& m = e.m;
+    e.lock_model();
+    Batch& b = *e.b;
+    const Desc& d = m.d;
+    hipStream_t s = e.io;   // beside the step chain, which keeps running on m.stream for the slots that are generating
+    const int turn = e.arena_turn;
+    e.arena_turn ^= 1;
+    UploadScope upload_scope(e.arenas[turn], e.arena_free[turn]);   // the copies queued from this arena two admissions ago are long done
+    const int B = e.B, D = d.d_model, ld = d.ldim;
+    std::vector<int> slot_of((size_t)n);
+    {
+        int next = 0;
+        for (int i = 0; i < n; i++) {
+            while (next < B && e.slots[(size_t)next].busy) next++;
+            if (next >= B) throw Error(PTTS_EINVAL, "continuous batch: more requests admitted than free slots");
+            slot_of[(size_t)i] = next++;
+        }
+    }
+    // voices: a free slot forgets its previous prefix first
+    std::map<const Voice*, std::vector<int32_t>> by_voice;
+    for (int i = 0; i < n; i++) {
+        const int sl = slot_of[(size_t)i];
+        b.kv_len_host[(size_t)sl] = 0;
+        b.pre_k_host[(size_t)sl] = nullptr; b.pre_v_host[(size_t)sl] = nullptr; b.pre_len_host[(size_t)sl] = 0;
+    }
+    for (int i = 0; i < n; i++) {
+        const ptts_request& r = *reqs[i];
+        const int sl = slot_of[(size_t)i];
+        if (r.voice) by_voice[reinterpret_cast<const Voice*>(r.voice)].push_back(sl);
+        else if (r.voice_caches) batch_set_voice(b, sl, r.voice_caches, r.voice_cache_steps, r.voice_offsets);
+    }
+    for (auto& kv : by_voice) batch_apply_voice(b, *kv.first, kv.second);
+    // prompt rows of the newcomers, packed; the running slots have empty segments
+    std::vector<int64_t> row_off((size_t)B + 1, 0);
+    std::vector<int> req_of_slot((size_t)B, -1);
+    for (int i = 0; i < n; i++) req_of_slot[(size_t)slot_of[(size_t)i]] = i;
+    for (int sl = 0; sl < B; sl++) {
+        const int i = req_of_slot[(size_t)sl];
+        const int64_t tp = i < 0 ? 0 : reqs[i]->n_tokens + (reqs[i]->voice_embedding ? reqs[i]->voice_frames : 0);
+        row_off[(size_t)sl + 1] = row_off[(size_t)sl] + tp;
+    }
+    const int64_t R = row_off[(size_t)B];
+    DevBuf& rows = m.work(5, (size_t)R * D * sizeof(float));
+    {
+        std::vector<int64_t> ids;
+        for (int sl = 0; sl < B; sl++) {
+            const int i = req_of_slot[(size_t)sl];
+            if (i >= 0) ids.insert(ids.end(), reqs[i]->tokens, reqs[i]->tokens + reqs[i]->n_tokens);
+        }
+        DevBuf& dids = m.work(6, ids.size() * sizeof(int64_t));
+        h2d(dids.p, ids.data(), ids.size() * sizeof(int64_t), s);
+        int64_t id0 = 0;
+        for (int sl = 0; sl < B; sl++) {   // (text embeddings and voice embeddings as GenerateAudio concatenates them, :89-119)
+            const int i = req_of_slot[(size_t)sl];
+            if (i < 0) continue;
+            const ptts_request& r = *reqs[i];
+            float* dst = rows.as<float>() + row_off[(size_t)sl] * D;
+            const int64_t tv = r.voice_embedding ? r.voice_frames : 0;
+            if (tv) h2d(dst, r.voice_embedding, (size_t)tv * D * sizeof(float), s);
+            launch_embed_gather(m.at<float>(d.embed), dids.as<int64_t>() + id0, (int)r.n_tokens, D, dst + tv * D, s);
+            id0 += r.n_tokens;
+        }
+    }
+    batch_prompt(b, rows.as<float>(), row_off.data());
+    // bookkeeping and noise rows of the new slots
+    std::vector<SlotAdmit> adm((size_t)n);
+    std::vector<NoiseSpec> spec((size_t)B, NoiseSpec{0, 0.0f, 0});
+    bool any_draw = false;
+    int draw_rows = 0;
+    for (int i = 0; i < n; i++) {
+        const ptts_request& r = *reqs[i];
+        const int sl = slot_of[(size_t)i];
+        const int ms = resolve_max_steps(r);
+        adm[(size_t)i] = SlotAdmit{sl, ms, r.frames_after_eos, r.eos_threshold, b.kv_len_host[(size_t)sl], b.pre_len_host[(size_t)sl], b.pre_k_host[(size_t)sl],
+                                   b.pre_v_host[(size_t)sl]};
+        float* nrow = b.noise.as<float>() + (size_t)sl * b.max_steps * ld;
+        PTTS_HIP(hipMemsetAsync(nrow, 0, (size_t)b.max_steps * ld * sizeof(float), s));
+        if (r.noise) h2d(nrow, r.noise, (size_t)ms * ld * sizeof(float), s);
+        else if (r.temperature > 0.0f) {
+            if (ld % 4) throw Error(PTTS_EINVAL, "ptts-hip: the device noise draw needs a latent width that is a multiple of 4");
+            spec[(size_t)sl] = NoiseSpec{r.noise_seed ? r.noise_seed : m.next_noise_seed(), std::sqrt(r.temperature), ms};
+            any_draw = true;
+            draw_rows = std::max(draw_rows, ms);
+        }
+    }
+    if (any_draw) {
+        DevBuf& sb = m.work(12, spec.size() * sizeof(NoiseSpec));
+        h2d(sb.p, spec.data(), spec.size() * sizeof(NoiseSpec), s);
+        launch_noise_fill(sb.as<NoiseSpec>(), B, draw_rows, b.noise.as<float>(), (int64_t)b.max_steps * ld, ld, s);
+    }
+    ContEngine::Joining j;
+    j.ring = e.adm_turn;
+    e.adm_turn = (e.adm_turn + 1) & 3;
+    h2d(e.adm_dev[j.ring].p, adm.data(), adm.size() * sizeof(SlotAdmit), s);
+    for (int i = 0; i < n; i++) {
+        ContEngine::Slot& sl = e.slots[(size_t)slot_of[(size_t)i]];
+        sl = ContEngine::Slot{};
+        sl.busy = true; sl.req = reqs[i]; sl.res = results[i]; sl.tag = tags[i];
+        sl.ms = adm[(size_t)i].max_steps;
+        sl.base_kv = b.kv_len_host[(size_t)slot_of[(size_t)i]];
+        sl.joining = true;
+        j.slots.push_back(slot_of[(size_t)i]);
+    }
+    j.ready = e.event();
+    PTTS_HIP(hipEventRecord(j.ready, s));
+    PTTS_HIP(hipEventRecord(e.arena_free[turn], s));   // (the requests' own host arrays stay valid until their callers are woken)
+    e.joining.push_back(std::move(j));
+    e.admissions++;
+    e.admitted += n;
+    e.last_admit_seq = e.seq;
+}
+
+// newcomers whose prefill has completed start stepping with the next group (activation is one small kernel on the step stream)
+static void activate_ready(ContEngine& e, bool wait) {
+    Batch& b = *e.b;
+    while (!e.joining.empty()) {
+        ContEngine::Joining& j = e.joining.front();
+        if (wait) PTTS_HIP(hipEventSynchronize(j.ready));
+        else {
+            hipError_t q = hipEventQuery(j.ready);
+            if (q == hipErrorNotReady) return;
+            if (q != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipEventQuery failed: %s", hipGetErrorString(q)));
+        }
+        launch_slot_admit(b.st, b.pre_len.as<int32_t>(), b.pre_k.as<const void*>(), b.pre_v.as<const void*>(), e.adm_dev[j.ring].as<SlotAdmit>(), (int)j.slots.size(),
+                          e.m.stream);
+        for (int sl : j.slots) { e.slots[(size_t)sl].joining = false; e.slots[(size_t)sl].admit_seq = e.seq; e.slots[(size_t)sl].seen_seq = e.seq; }
+        e.n_gen += (int)j.slots.size();
+        e.free_events.push_back(j.ready);
+        e.joining.pop_front();
+    }
+}
+
+// ended utterances -> audio, on the second stream, from their staging rows (which return to the pool when the frames have been packed)
+static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
+    Model& m = e.m;
+    Batch& b = *e.b;
+    const Desc& d = m.d;
+    const int ld = d.ldim;
+    const int64_t spf = d.samples_per_frame;
+    hipStream_t s = m.stream, s2 = m.stream2;
+    PTTS_HIP(hipEventRecord(e.ev_steps, s));            // the staging copies were queued on the AR stream
+    PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
+    std::sort(fin.begin(), fin.end(), [](const ContEngine::Staged& x, const ContEngine::Staged& y) { return x.nf > y.nf; });   // like lengths together: less padding
+    size_t at = 0;
+    while (at < fin.size()) {
+        size_t end = at;
+        int T = 0;
+        while (end < fin.size()) {   // a sub-group whose decode fits the workspace
+            const int t2 = std::max(T, std::max(1, fin[end].nf));
+            if (end > at && (int64_t)t2 * (int64_t)(end - at + 1) > kFramesPerDecode) break;
+            T = t2; end++;
+        }
+        const int nb = (int)(end - at);
+        DevBuf& lat = m.work(13, (size_t)nb * T * ld * sizeof(float));
+        PTTS_HIP(hipMemsetAsync(lat.p, 0, (size_t)nb * T * ld * sizeof(float), s2));
+        for (int i = 0; i < nb; i++) {
+            const ContEngine::Staged& f = fin[at + (size_t)i];
+            if (f.nf > 0)
+                PTTS_HIP(hipMemcpyAsync(lat.as<float>() + (size_t)i * T * ld, e.stage.as<float>() + (size_t)f.row * b.max_steps * ld, (size_t)f.nf * ld * sizeof(float),
+                                        hipMemcpyDeviceToDevice, s2));
+        }
+        if (end == fin.size()) {   // the staging rows are read: the AR stream may refill them
+            PTTS_HIP(hipEventRecord(e.ev_gather, s2));
+            PTTS_HIP(hipStreamWaitEvent(s, e.ev_gather, 0));
+        }
+        MimiWs mw;
+        mimi_setup(m, mw, nb, T);
+        mimi_zero_history(m, mw, s2);
+        DevBuf& pcm = m.work(7, (size_t)nb * T * spf * sizeof(float));
+        mimi_range(m, mw, lat.as<float>(), (int64_t)T * ld, 0, T, pcm.as<float>(), nullptr, s2);
+        bool any_s16 = false;
+        for (int i = 0; i < nb; i++) any_s16 |= fin[at + (size_t)i].req->pcm_format == PTTS_PCM_S16;
+        DevBuf* s16 = nullptr;
+        if (any_s16) {
+            s16 = &m.work(8, (size_t)nb * T * spf * sizeof(int16_t));
+            launch_pcm16(pcm.as<float>(), s16->as<int16_t>(), (int64_t)nb * T * spf, s2);
+        }
+        ContEngine::Pending p;
+        for (int i = 0; i < nb; i++) {
+            const ContEngine::Staged& f = fin[at + (size_t)i];
+            ptts_result& r = *f.res;
+            const int nf = f.nf;
+            r.n_frames = nf; r.eos_step = f.eos; r.n_samples = (int64_t)nf * spf; r.status = PTTS_OK;
+            if (f.req->pcm_format == PTTS_PCM_S16) {
+                r.pcm16 = (int16_t*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(int16_t));
+                if (!r.pcm16) r.status = PTTS_ENOMEM;
+                else if (r.n_samples > 0)
+                    PTTS_HIP(hipMemcpyAsync(r.pcm16, s16->as<int16_t>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(int16_t), hipMemcpyDeviceToHost, s2));
+            } else {
+                r.pcm = (float*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
+                if (!r.pcm) r.status = PTTS_ENOMEM;
+                else if (r.n_samples > 0)
+                    PTTS_HIP(hipMemcpyAsync(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), hipMemcpyDeviceToHost, s2));
+            }
+            if (f.req->want_latents && r.status == PTTS_OK) {
+                r.latents = (float*)malloc((size_t)std::max(1, nf) * ld * sizeof(float));
+                if (!r.latents) r.status = PTTS_ENOMEM;
+                else if (nf > 0)
+                    PTTS_HIP(hipMemcpyAsync(r.latents, lat.as<float>() + (size_t)i * T * ld, (size_t)nf * ld * sizeof(float), hipMemcpyDeviceToHost, s2));
+            }
+            p.tags.push_back(f.tag);
+            p.res.push_back(f.res);
+            e.stage_free.push_back(f.row);
+        }
+        p.done = e.event();
+        PTTS_HIP(hipEventRecord(p.done, s2));
+        e.decoding.push_back(std::move(p));
+        at = end;
+    }
+    fin.clear();
+}
+
+// what one read-back says about the slots it covers: ended utterances are marked (their frames wait for the decoder), cancelled ones are
+// answered at once and switched off
+static void take_snapshot(ContEngine& e, ContEngine::Snap& sn, std::vector<void*>& done) {
+    Model& m = e.m;
+    Batch& b = *e.b;
+    const int B = e.B;
+    PTTS_HIP(hipEventSynchronize(sn.ready));
+    sn.pending = false;
+    const int32_t* active = sn.host;
+    const int32_t* n_frames = sn.host + 3 * (size_t)B;
+    const int32_t* eos_step = sn.host + 4 * (size_t)B;
+    std::vector<int32_t> retire;
+    for (int sl = 0; sl < B; sl++) {
+        ContEngine::Slot& so = e.slots[(size_t)sl];
+        if (!so.busy || so.joining || sn.seq <= so.admit_seq) continue;   // (a read-back from before the slot was filled says nothing about it)
+        so.nf_seen = n_frames[sl]; so.seen_seq = sn.seq;
+        if (so.req->cancel && *so.req->cancel) {   // ctx.Err() between steps (runtime_native_safetensors.go:156-159)
+            retire.push_back(sl);
+            so.res->status = PTTS_ECANCELLED;
+            done.push_back(so.tag);
+            so = ContEngine::Slot{};
+            e.n_gen--;
+        } else if (!active[sl]) {   // ended: its frames move to a staging row (queued behind the group in flight), the slot is free
+            const int nf = n_frames[sl], ld = m.d.ldim;
+            if (e.stage_free.empty()) { start_decode(e, e.staged); }   // (cannot run dry before this: 2 B rows, at most B slots + what one turn adds)
+            const int row = e.stage_free.back();
+            e.stage_free.pop_back();
+            if (nf > 0)
+                PTTS_HIP(hipMemcpyAsync(e.stage.as<float>() + (size_t)row * b.max_steps * ld, b.latents.as<float>() + (size_t)sl * b.max_steps * ld, (size_t)nf * ld * sizeof(float),
+                                        hipMemcpyDeviceToDevice, m.stream));
+            e.staged.push_back(ContEngine::Staged{so.req, so.res, so.tag, nf, eos_step[sl], row, e.seq});
+            so = ContEngine::Slot{};
+            e.n_gen--;
+        }
+    }
+    if (!retire.empty()) {   // queued behind the group in flight; whatever refills the slot is queued behind this
+        const int turn = e.arena_turn;
+        e.arena_turn ^= 1;
+        UploadScope upload_scope(e.arenas[turn], e.arena_free[turn]);
+        DevBuf& dr = m.work(15, (size_t)B * sizeof(int32_t));
+        h2d(dr.p, retire.data(), retire.size() * sizeof(int32_t), m.stream);
+        launch_slot_retire(b.st, dr.as<int32_t>(), (int)retire.size(), m.stream);
+        PTTS_HIP(hipEventRecord(e.arena_free[turn], m.stream));
+    }
+}
+
+// One turn of the engine: a group of `steps` AR steps is queued (if anything is generating) and its read-back behind it; the read-back of
+// the PREVIOUS group -- complete by now -- is looked at; finished utterances are handed to the decoder a handful at a time; `done`
+// receives the tags whose results are complete (status set).  drain: do not return before everything in flight has been answered.
+void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain) {
+    Model& m = e.m;
+    if (e.busy() == 0) return;
+    e.lock_model();
+    Batch& b = *e.b;
+    const int B = e.B;
+    hipStream_t s = m.stream;
+    steps = std::max(1, steps);
+    e.group_steps = steps;
+    do {
+        activate_ready(e, e.n_gen == 0);   // (nothing generating: the newcomers are all there is to wait for)
+        if (e.n_gen > 0) {
+            // upper bound on any live slot's cache length when this group runs (the step attention issues load rounds by it)
+            int bound = 0;
+            for (int sl = 0; sl < B; sl++) {
+                const ContEngine::Slot& so = e.slots[(size_t)sl];
+                if (so.busy && !so.joining) bound = std::max(bound, so.base_kv + std::min(so.ms, so.nf_seen + steps * (int)(e.seq - so.seen_seq)));
+            }
+            b.kv_bound = std::min(bound, e.cap);
+            if (e.use_graph) enqueue_step(b, 1, true, steps);
+            else for (int k = 0; k < steps; k++) enqueue_step(b, 1, false, 1);
+            e.seq++;
+            ContEngine::Snap& sn = e.snaps[e.seq & 1];
+            if (sn.pending) take_snapshot(e, sn, done);   // (cannot happen: the older read-back is consumed every turn)
+            PTTS_HIP(hipMemcpyAsync(sn.host, b.st.active, (size_t)5 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            PTTS_HIP(hipEventRecord(sn.ready, s));
+            sn.seq = e.seq; sn.pending = true;
+        }
+        // the older read-back first; the newest as well when nothing else will be queued behind it
+        ContEngine::Snap& older = e.snaps[(e.seq + 1) & 1];
+        if (older.pending) take_snapshot(e, older, done);
+        ContEngine::Snap& newest = e.snaps[e.seq & 1];
+        if (newest.pending && (drain || e.n_gen == 0)) take_snapshot(e, newest, done);
+        // decode: a good handful at a time (small decodes are inefficient and disturb the step chain as much as large ones), or whatever
+        // there is once the oldest has waited eight groups / nothing generates / the caller drains
+        if (!e.staged.empty()) {
+            uint64_t oldest = e.seq;
+            for (const ContEngine::Staged& f : e.staged) oldest = std::min(oldest, f.seq);
+            if ((int)e.staged.size() >= std::max(4, B / 3) || e.seq - oldest >= 8 || e.n_gen == 0 || drain) start_decode(e, e.staged);
+        }
+        while (!e.decoding.empty()) {
+            ContEngine::Pending& p = e.decoding.front();
+            if (drain || (e.n_gen == 0 && e.n_finished() == 0)) PTTS_HIP(hipEventSynchronize(p.done));
+            else {
+                hipError_t q = hipEventQuery(p.done);
+                if (q == hipErrorNotReady) break;
+                if (q != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipEventQuery failed: %s", hipGetErrorString(q)));
+            }
+            for (void* t : p.tags) done.push_back(t);
+            e.free_events.push_back(p.done);
+            p.done = nullptr;
+            e.decoding.pop_front();
+        }
+    } while (drain && e.busy() > 0);
+    e.unlock_if_idle();
+}
+
+// newcomers are admitted at once into an engine with nothing generating, otherwise every fourth group (a prefill interrupts the step
+// chain of everyone else for ~0.5 ms however few rows it has), or as soon as a quarter of the slots can be filled in one go
+bool cont_admit_now(const ContEngine& e, int waiting) {
+    if (waiting <= 0 || e.free_slots() == 0) return false;
+    if (e.n_gen == 0) return true;
+    if (e.seq - e.last_admit_seq >= 4) return true;
+    return std::min(waiting, e.free_slots()) >= std::max(1, e.B / 4);
+}
+
+// every request in flight is answered with `code` (the engine is about to be torn down after an error)
+void cont_abort(ContEngine& e, int code, std::vector<void*>& done) {
+    (void)hipStreamSynchronize(e.m.stream);
+    (void)hipStreamSynchronize(e.m.stream2);
+    if (e.io) (void)hipStreamSynchronize(e.io);
+    for (auto& j : e.joining) if (j.ready) e.free_events.push_back(j.ready);
+    e.joining.clear();
+    for (ContEngine::Snap& sn : e.snaps) sn.pending = false;
+    for (auto& so : e.slots) {
+        if (!so.busy) continue;
+        so.res->status = code;
+        done.push_back(so.tag);
+        so = ContEngine::Slot{};
+    }
+    e.n_gen = 0;
+    for (auto& f : e.staged) { f.res->status = code; done.push_back(f.tag); e.stage_free.push_back(f.row); }
+    e.staged.clear();
+    for (auto& p : e.decoding) {
+        for (size_t i = 0; i < p.tags.size(); i++) { ptts_free_result(p.res[i]); p.res[i]->status = code; p.res[i]->eos_step = -1; done.push_back(p.tags[i]); }
+        if (p.done) { e.free_events.push_back(p.done); p.done = nullptr; }
+    }
+    e.decoding.clear();
+    e.unlock_if_idle();
+}
+
+}  // namespace ptts

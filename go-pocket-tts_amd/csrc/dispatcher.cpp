@@ -49,11 +49,16 @@ struct Dispatcher {
     Clock::time_point last_batch_left = Clock::now();
     bool collecting = false;            // one worker at a time forms a batch; the others wait their turn
     std::vector<std::thread> workers;
+    // continuous batching (continuous.cpp): one long-lived batch per model; free slots are refilled between groups of AR steps
+    bool continuous = false;
+    int cont_kv_cap = 512, cont_max_steps = 256, cont_group = 5;
     // statistics
     int64_t n_requests = 0, n_batches = 0, n_cancelled_waiting = 0, max_depth = 0;
     double sum_wait_us = 0.0, sum_exec_us = 0.0;
 
     void run(int w);
+    void run_continuous(int w);
+    void run_batch(Model* model, int w, std::vector<DispatchItem*>& batch);
 };
 
 static bool cancelled(const DispatchItem* it) { return it->req->cancel && *it->req->cancel; }
@@ -115,6 +120,13 @@ void Dispatcher::run(int w) {
             n_batches++;
             n_requests += (int64_t)batch.size();
         }
+        run_batch(model, w, batch);
+    }
+}
+
+// one batched generate for the collected requests; every caller is woken with its own result
+void Dispatcher::run_batch(Model* model, int w, std::vector<DispatchItem*>& batch) {
+    {
         std::vector<ptts_request> reqs(batch.size());
         std::vector<ptts_result> ress(batch.size());
         for (size_t i = 0; i < batch.size(); i++) reqs[i] = *batch[i]->req;
@@ -153,7 +165,117 @@ void Dispatcher::run(int w) {
     }
 }
 
-Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, void* user, int n_workers, int max_batch, int window_us, int queue_cap) {
+// Continuous batching: this worker owns one long-lived batch on its model.  Each turn: answer what was cancelled while waiting, move
+// waiting requests the engine can take into its free slots (prefill + bookkeeping), run a group of AR steps, read the counters back,
+// start the decoder on whatever ended, wake the callers whose audio has arrived.  Requests the engine cannot take (per-step callbacks,
+// streaming, lsd_steps > 1, budgets beyond its geometry) are run batch-at-a-time whenever the engine is empty; once such a request has
+// waited 50 ms the engine stops admitting until it has drained, so that it cannot starve.
+void Dispatcher::run_continuous(int w) {
+    Model* model = models[(size_t)w];
+    model->use_device();
+    std::unique_ptr<ContEngine, void (*)(ContEngine*)> eng(nullptr, cont_destroy);
+    auto fail_all = [&](std::vector<void*>& tags, int code, const std::string& msg) {
+        std::lock_guard<std::mutex> lock(mu);
+        for (void* t : tags) {
+            DispatchItem* d = static_cast<DispatchItem*>(t);
+            d->rc = code; d->err = msg; d->res->status = code; d->done = true; d->cv.notify_one();
+        }
+    };
+    try {   // the engine's buffers (KV caches, the decoder's workspace) exist before the first caller arrives
+        eng.reset(cont_create(*model, std::min(max_batch, std::max(1, model->opts.max_batch)), cont_kv_cap, cont_max_steps));
+    } catch (const std::exception&) {}   // (retried, and reported to the callers, in the loop)
+    for (;;) {
+        std::vector<DispatchItem*> take, classic;
+        try {
+            if (!eng) eng.reset(cont_create(*model, std::min(max_batch, std::max(1, model->opts.max_batch)), cont_kv_cap, cont_max_steps));
+            const int busy = cont_busy(*eng);
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                auto eligible = [&](const DispatchItem* it) { return !it->voice || voice_usable_by(*it->voice, *model); };
+                auto any_eligible = [&] { for (DispatchItem* it : queue) if (eligible(it)) return true; return false; };
+                if (busy == 0) {
+                    cv_work.wait(lock, [&] { return closing || any_eligible(); });
+                    if (!any_eligible()) { if (closing) return; continue; }
+                    // an idle engine gives a burst the same short window as the batch collector before it starts stepping
+                    const Clock::time_point t_first = Clock::now();
+                    const auto window = std::chrono::microseconds(window_us);
+                    while (!closing && (int)queue.size() < max_batch && Clock::now() < t_first + window) cv_work.wait_until(lock, t_first + window);
+                }
+                const Clock::time_point now = Clock::now();
+                bool classic_waiting_long = false;
+                for (DispatchItem* it : queue)
+                    if (eligible(it) && !cont_accepts(*eng, *it->req) && now - it->enq > std::chrono::milliseconds(50)) classic_waiting_long = true;
+                // an empty engine serves the oldest waiting request in the way that request needs: batch-at-a-time if it cannot be taken
+                bool classic_mode = false;
+                if (busy == 0)
+                    for (DispatchItem* it : queue)
+                        if (eligible(it) && !cancelled(it)) { classic_mode = !cont_accepts(*eng, *it->req); break; }
+                int n_fit = 0;
+                for (DispatchItem* it : queue) n_fit += eligible(it) && !cancelled(it) && cont_accepts(*eng, *it->req);
+                int room = (classic_waiting_long || classic_mode || !cont_admit_now(*eng, n_fit)) ? 0 : cont_free_slots(*eng);
+                for (auto it = queue.begin(); it != queue.end();) {
+                    DispatchItem* d = *it;
+                    if (!eligible(d)) { ++it; continue; }
+                    if (cancelled(d)) {
+                        it = queue.erase(it);
+                        d->rc = PTTS_ECANCELLED; d->err = "request cancelled while waiting for worker"; d->done = true;
+                        n_cancelled_waiting++;
+                        d->cv.notify_one();
+                        continue;
+                    }
+                    const bool fits = cont_accepts(*eng, *d->req);
+                    if (fits && room > 0) {
+                        it = queue.erase(it); take.push_back(d); room--;
+                        sum_wait_us += std::chrono::duration<double, std::micro>(now - d->enq).count();
+                        continue;
+                    }
+                    if (!fits && classic_mode && (int)classic.size() < max_batch) {
+                        it = queue.erase(it); classic.push_back(d);
+                        sum_wait_us += std::chrono::duration<double, std::micro>(now - d->enq).count();
+                        continue;
+                    }
+                    ++it;
+                }
+                if (!take.empty()) { n_batches++; n_requests += (int64_t)take.size(); }
+                else if (!classic.empty()) { n_batches++; n_requests += (int64_t)classic.size(); }
+            }
+            if (take.empty() && !classic.empty()) { run_batch(model, w, classic); continue; }
+            const Clock::time_point t0 = Clock::now();
+            if (!take.empty()) {
+                std::vector<const ptts_request*> rq; std::vector<ptts_result*> rs; std::vector<void*> tg;
+                for (DispatchItem* d : take) { rq.push_back(d->req); rs.push_back(d->res); tg.push_back(d); }
+                cont_admit(*eng, rq.data(), rs.data(), tg.data(), (int)take.size());
+                take.clear();
+            }
+            std::vector<void*> done;
+            cont_advance(*eng, cont_group, done, false);
+            const double exec_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count();
+            if (!done.empty() || exec_us > 0) {
+                std::lock_guard<std::mutex> lock(mu);
+                sum_exec_us += exec_us;
+                for (void* t : done) {
+                    DispatchItem* d = static_cast<DispatchItem*>(t);
+                    d->rc = d->res->status;
+                    if (d->rc == PTTS_ECANCELLED) d->err = "context canceled";
+                    else if (d->rc != PTTS_OK) d->err = "generate: request failed";
+                    d->done = true;
+                    d->cv.notify_one();
+                }
+            }
+        } catch (const std::exception& ex) {   // a HIP error or a malformed request that slipped through: everyone in flight is told, the engine is rebuilt
+            const Error* pe = dynamic_cast<const Error*>(&ex);
+            const int code = pe ? pe->code : PTTS_EINVAL;
+            std::vector<void*> tags;
+            for (DispatchItem* d : take) tags.push_back(d);
+            if (eng) cont_abort(*eng, code, tags);
+            fail_all(tags, code, ex.what());
+            eng.reset();
+        }
+    }
+}
+
+Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, void* user, int n_workers, int max_batch, int window_us, int queue_cap,
+                              const DispatchCont* cont) {
     std::unique_ptr<Dispatcher> d(new Dispatcher());
     if (exec) {
         d->exec = exec; d->exec_user = user; d->n_workers = std::max(1, n_workers);
@@ -169,7 +291,13 @@ Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, v
     d->max_batch = std::max(1, max_batch <= 0 ? 64 : max_batch);
     d->window_us = std::max(0, window_us);
     d->queue_cap = queue_cap <= 0 ? 4096 : queue_cap;
-    for (int w = 0; w < d->n_workers; w++) d->workers.emplace_back([p = d.get(), w] { p->run(w); });
+    if (cont && cont->on && !exec) {
+        d->continuous = true;
+        if (cont->kv_capacity > 0) d->cont_kv_cap = cont->kv_capacity;
+        if (cont->max_steps > 0) d->cont_max_steps = cont->max_steps;
+        if (cont->steps_per_group > 0) d->cont_group = cont->steps_per_group;
+    }
+    for (int w = 0; w < d->n_workers; w++) d->workers.emplace_back([p = d.get(), w] { if (p->continuous) p->run_continuous(w); else p->run(w); });
     return d.release();
 }
 

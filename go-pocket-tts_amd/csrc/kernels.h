@@ -262,6 +262,10 @@ void launch_step_finish(const StepState& s, const float* frame, const float* eos
 // N(0,1) * spec[b].sigma, a function of (spec[b].seed, row, element) only; rows == 0 leaves the slot untouched.  ldim % 4 == 0.
 struct NoiseSpec { uint64_t seed; float sigma; int32_t rows; };
 void launch_noise_fill(const NoiseSpec* spec_dev, int n_slots, int max_rows, float* out, int64_t out_stride, int ldim, hipStream_t stream);
+// continuous batching: (re)initialise the bookkeeping of the slots a new utterance moves into; switch cancelled slots off
+struct SlotAdmit { int32_t slot, max_steps, frames_after_eos; float eos_threshold; int32_t kv_len, pre_len; const void* pre_k; const void* pre_v; };
+void launch_slot_admit(const StepState& s, int32_t* pre_len, const void** pre_k, const void** pre_v, const SlotAdmit* dev, int n, hipStream_t stream);
+void launch_slot_retire(const StepState& s, const int32_t* slots_dev, int n, hipStream_t stream);
 void launch_fill_i32(int32_t* p, int32_t v, int n, hipStream_t stream);
 void launch_add_i32(int32_t* p, const int32_t* inc, int n, hipStream_t stream);
 

@@ -246,6 +246,30 @@ void launch_add_i32(int32_t* p, const int32_t* inc, int n, hipStream_t stream) {
     hipLaunchKernelGGL(k_add_i32, dim3((n + 255) / 256), dim3(256), 0, stream, p, inc, n);
 }
 
+// Continuous batching (continuous.cpp): a slot of a running batch is handed to a new utterance / taken from one that was cancelled.
+// One thread per slot touched; the live-utterance counter moves by the number of slots whose `active` flag changes.
+__global__ void k_slot_admit(StepState s, int32_t* pre_len, const void** pre_k, const void** pre_v, const SlotAdmit* a, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sl = a[i].slot;
+    s.kv_len[sl] = a[i].kv_len; pre_len[sl] = a[i].pre_len; pre_k[sl] = a[i].pre_k; pre_v[sl] = a[i].pre_v;
+    s.active[sl] = 1; s.step[sl] = 0; s.countdown[sl] = -1; s.n_frames[sl] = 0; s.eos_step[sl] = -1; s.broke[sl] = 0;
+    s.max_steps[sl] = a[i].max_steps; s.frames_after_eos[sl] = a[i].frames_after_eos; s.eos_threshold[sl] = a[i].eos_threshold;
+    if (i == 0) atomicAdd(s.n_active, n);
+}
+void launch_slot_admit(const StepState& s, int32_t* pre_len, const void** pre_k, const void** pre_v, const SlotAdmit* dev, int n, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(k_slot_admit, dim3((n + 63) / 64), dim3(64), 0, stream, s, pre_len, pre_k, pre_v, dev, n);
+}
+__global__ void k_slot_retire(StepState s, const int32_t* slots, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int sl = slots[i];
+    if (s.active[sl]) { s.active[sl] = 0; atomicSub(s.n_active, 1); }
+}
+void launch_slot_retire(const StepState& s, const int32_t* slots_dev, int n, hipStream_t stream) {
+    if (n > 0) hipLaunchKernelGGL(k_slot_retire, dim3((n + 63) / 64), dim3(64), 0, stream, s, slots_dev, n);
+}
+
 // ------------------------------------------------------------------------------------------------
 // RoPE on rows of a qkv buffer (K5; rope.go:81-105): interleaved pairs, table row = position
 // ------------------------------------------------------------------------------------------------

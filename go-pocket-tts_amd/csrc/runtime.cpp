@@ -38,19 +38,22 @@ static LnArgs mkln(const Model& m, const float* x, RowMap xm, const Norm& n, flo
 // (~20 us each, a dozen per call).  Inside generate_chunk they are staged through a page-locked arena instead and queued
 // without a wait; the arena is rewound when the call starts (the previous call ended with the stream drained).
 static thread_local UploadArena* tl_upload = nullptr;
-namespace {
-struct UploadScope {   // generate_chunk: uploads of this thread go through m.upload until the scope ends
-    UploadScope(UploadArena& a, hipStream_t s) {
-        (void)hipStreamSynchronize(s);   // normally idle already; after a failed call it may still be reading the arena
-        if (!a.base && hipHostMalloc((void**)&a.base, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) a.cap = (size_t)1 << 20;
-        else if (!a.base) (void)hipGetLastError();
-        a.off = 0;
-        tl_upload = &a;
-    }
-    ~UploadScope() { tl_upload = nullptr; }
-};
-}  // namespace
-static void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
+UploadScope::UploadScope(UploadArena& a, hipStream_t s) {   // uploads of this thread go through the arena until the scope ends
+    (void)hipStreamSynchronize(s);   // normally idle already; after a failed call it may still be reading the arena
+    if (!a.base && hipHostMalloc((void**)&a.base, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) a.cap = (size_t)1 << 20;
+    else if (!a.base) (void)hipGetLastError();
+    a.off = 0;
+    tl_upload = &a;
+}
+UploadScope::UploadScope(UploadArena& a, hipEvent_t last_use) {   // an arena of its own, reused once the copies queued from it last time are done
+    if (last_use) (void)hipEventSynchronize(last_use);
+    if (!a.base && hipHostMalloc((void**)&a.base, (size_t)1 << 20, hipHostMallocDefault) == hipSuccess) a.cap = (size_t)1 << 20;
+    else if (!a.base) (void)hipGetLastError();
+    a.off = 0;
+    tl_upload = &a;
+}
+UploadScope::~UploadScope() { tl_upload = nullptr; }
+void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
     UploadArena* a = tl_upload;
     const size_t need = (bytes + 63) & ~(size_t)63;
@@ -64,7 +67,7 @@ static void h2d(void* dst, const void* src, size_t bytes, hipStream_t s) {
     PTTS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, s));
     PTTS_HIP(hipStreamSynchronize(s));
 }
-static void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
+void d2h(void* dst, const void* src, size_t bytes, hipStream_t s) {
     if (!bytes) return;
     PTTS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
     PTTS_HIP(hipStreamSynchronize(s));
@@ -294,44 +297,48 @@ bool voice_usable_by(const Voice& v, const Model& m) {
 
 void batch_apply_voice(Batch& b, const Voice& v, const std::vector<int32_t>& slots) {
     Model& m = *b.m;
+    hipStream_t io = b.io_stream ? b.io_stream : m.stream;
     const Desc& d = m.d;
     if (!voice_usable_by(v, m)) throw Error(PTTS_EINVAL, "ptts-hip: voice belongs to another model");
     if (v.offset > b.cap) throw Error(PTTS_EINVAL, "ptts-hip: voice state longer than the KV capacity");
     DevBuf& ds = m.work(10, slots.size() * sizeof(int32_t));
-    h2d(ds.p, slots.data(), slots.size() * sizeof(int32_t), m.stream);
+    h2d(ds.p, slots.data(), slots.size() * sizeof(int32_t), io);
     const size_t lb = v.layer_bytes();
     for (int l = 0; l < d.n_layers; l++)
         launch_voice_apply((const char*)v.k.p + lb * l, (const char*)v.v.p + lb * l, v.offset, d.heads, d.hd, ds.as<int32_t>(), (int)slots.size(),
-                           b.kc(l), b.vc(l), (int)b.kv_elem(), b.cap, m.stream);
+                           b.kc(l), b.vc(l), (int)b.kv_elem(), b.cap, io);
     for (int32_t sl : slots) {
         b.kv_len_host[sl] = v.offset;
         b.kv_bound = std::max(b.kv_bound, (int)v.offset);
         b.pre_k_host[sl] = v.k.p; b.pre_v_host[sl] = v.v.p; b.pre_len_host[sl] = v.offset;
     }
-    h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)b.B * sizeof(int32_t), m.stream);
-    h2d(b.pre_k.p, b.pre_k_host.data(), (size_t)b.B * sizeof(void*), m.stream);
-    h2d(b.pre_v.p, b.pre_v_host.data(), (size_t)b.B * sizeof(void*), m.stream);
-    h2d(b.pre_len.p, b.pre_len_host.data(), (size_t)b.B * sizeof(int32_t), m.stream);
+    if (b.slot_local) return;   // continuous batch: the admit kernel writes these entries for the slots it fills; the others are live
+    h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)b.B * sizeof(int32_t), io);
+    h2d(b.pre_k.p, b.pre_k_host.data(), (size_t)b.B * sizeof(void*), io);
+    h2d(b.pre_v.p, b.pre_v_host.data(), (size_t)b.B * sizeof(void*), io);
+    h2d(b.pre_len.p, b.pre_len_host.data(), (size_t)b.B * sizeof(int32_t), io);
 }
 
 void batch_set_voice(Batch& b, int slot, const float* const* caches, const int64_t* steps, const int64_t* offsets) {
     Model& m = *b.m;
+    hipStream_t io = b.io_stream ? b.io_stream : m.stream;
     const Desc& d = m.d;
     if (slot < 0 || slot >= b.B) throw Error(PTTS_EINVAL, "ptts-hip: voice state slot out of range");
     check_voice(d, caches, steps, offsets, b.cap);
     for (int l = 0; l < d.n_layers; l++) {
         size_t n = (size_t)2 * steps[l] * d.heads * d.hd;
         DevBuf& raw = m.work(1, n * sizeof(float));
-        h2d(raw.p, caches[l], n * sizeof(float), m.stream);
+        h2d(raw.p, caches[l], n * sizeof(float), io);
         launch_voice_scatter(raw.as<float>(), (int)steps[l], d.heads, d.hd, (int)offsets[l], slot, b.kc(l), b.vc(l),
-                             m.opts.kv == PTTS_KV_BF16, b.cap, m.stream);
-        PTTS_HIP(hipStreamSynchronize(m.stream));
+                             m.opts.kv == PTTS_KV_BF16, b.cap, io);
+        PTTS_HIP(hipStreamSynchronize(io));
     }
     b.kv_len_host[slot] = (int32_t)offsets[0];
     b.kv_bound = std::max(b.kv_bound, (int)offsets[0]);
-    h2d(b.st.kv_len + slot, &b.kv_len_host[slot], sizeof(int32_t), m.stream);
     b.pre_len_host[slot] = 0;
-    h2d(b.pre_len.as<int32_t>() + slot, &b.pre_len_host[slot], sizeof(int32_t), m.stream);
+    if (b.slot_local) return;
+    h2d(b.st.kv_len + slot, &b.kv_len_host[slot], sizeof(int32_t), io);
+    h2d(b.pre_len.as<int32_t>() + slot, &b.pre_len_host[slot], sizeof(int32_t), io);
 }
 
 // FlowLM.PromptText -> flowTransformer.prefill (flow_lm.go:155-187, flow_transformer.go:749-771), all slots at once,
@@ -342,7 +349,7 @@ static int pick_split(int M, int N, int K, bool w_bf16 = false);
 void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
     Model& m = *b.m;
     const Desc& d = m.d;
-    hipStream_t s = m.stream;
+    hipStream_t s = b.io_stream ? b.io_stream : m.stream;
     const int B = b.B, D = d.d_model;
     const int64_t R64 = row_offsets[B];
     if (R64 == 0) return;
@@ -458,7 +465,7 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
         b.kv_len_host[sl] += (int32_t)(row_offsets[sl + 1] - row_offsets[sl]);
         b.kv_bound = std::max(b.kv_bound, (int)b.kv_len_host[sl]);
     }
-    h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)B * sizeof(int32_t), s);
+    if (!b.slot_local) h2d(b.st.kv_len, b.kv_len_host.data(), (size_t)B * sizeof(int32_t), s);
 }
 
 // every linear of the AR step goes through here so that bench.py can time the dominant kernel with HIP events
@@ -748,7 +755,7 @@ void mimi_setup(Model& m, MimiWs& w, int B, int T) {
     w.zeroed = false;
 }
 
-static void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
+void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
     const Desc& d = m.d;
     const int C = d.mimi_dim, T1 = w.Ls[0];
     launch_zero_rows(w.xp, (int64_t)(1 + w.T) * C, w.B, C, s);
@@ -977,7 +984,7 @@ void result_free(void* p) {
 // ------------------------------------------------------------------------------------------------
 // GenerateAudio for a batch of independent utterance chunks
 // ------------------------------------------------------------------------------------------------
-static int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go:61-67, text/prepare.go:38-48
+int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go:61-67, text/prepare.go:38-48
     int ms = r.max_steps;
     if (ms <= 0) ms = r.estimated_max_steps;
     if (ms <= 0) ms = (int)std::ceil(((double)r.n_tokens / 3.0 + 2.0) * 12.5);
@@ -1023,7 +1030,7 @@ static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
 }
 
 // nsteps > 1 only with use_graph
-static void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps = 1) {
+void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps) {
     Model& m = *b.m;
     if (use_graph) {
         const int ni = attn_step_rounds(std::min(b.kv_bound + nsteps, b.cap), m.opts.kv == PTTS_KV_BF16);

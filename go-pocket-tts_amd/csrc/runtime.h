@@ -110,6 +110,8 @@ struct Batch {
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;
     bool opened = false;     // the last step_open also produced x and fx
+    hipStream_t io_stream = nullptr;   // continuous batch: voice ingestion and prefill of newcomers run here, beside the step chain on the model's stream
+    bool slot_local = false; // continuous batch: per-slot device state (kv_len, voice prefix) is written slot by slot by the admit kernel, never as whole arrays
     // host-side upper bound on the cache length of any slot (set by voice/prompt ingestion, +1 per step): lets a step's
     // attention launch issue only the key loads that can be live (AttnArgs::keys_now).  capturing: a graph is being recorded,
     // its launches must cover the whole cache
@@ -178,6 +180,13 @@ bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = 
 void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 // xformer_out (optional, staged parity checks): the decoder transformer's output rows [B][T * up_stride][mimi_dim]
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev, float* xformer_out = nullptr);
+// pieces of the generate loop that the continuous batch (continuous.cpp) reuses
+struct UploadScope { UploadScope(UploadArena& a, hipStream_t s); UploadScope(UploadArena& a, hipEvent_t last_use); ~UploadScope(); };   // small uploads of this thread are staged page-locked, no waits
+void h2d(void* dst, const void* src, size_t bytes, hipStream_t s);
+void d2h(void* dst, const void* src, size_t bytes, hipStream_t s);
+int resolve_max_steps(const ptts_request& r);                                   // runtime_native_safetensors.go:61-67
+void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps = 1);           // nsteps > 1 only with use_graph
+void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s);
 Model* model_share(Model& base);   // another engine over base's weight arena (base must outlive it)
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
 std::string request_error(const Desc& d, const ptts_request& q);   // empty: the request is well formed
@@ -216,10 +225,24 @@ void dsp_fade_out(float* s, int64_t n, int sample_rate, double ms);
 void rccl_unique_id(uint8_t out[128]);
 void rccl_broadcast(void* device_buf, size_t bytes, int rank, int n_ranks, const uint8_t id[128], int device);
 
+// continuous batch of one model (continuous.cpp): fixed slots / KV capacity / step budget; used by the dispatcher's continuous mode
+struct ContEngine;
+ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps);
+void cont_destroy(ContEngine* e);
+bool cont_accepts(const ContEngine& e, const ptts_request& r);   // fits the geometry and needs no per-step host work
+int cont_free_slots(const ContEngine& e);
+int cont_busy(const ContEngine& e);                               // utterances generating + groups being decoded
+bool cont_admit_now(const ContEngine& e, int waiting);              // admission pacing: see continuous.cpp
+void cont_admit(ContEngine& e, const ptts_request* const* reqs, ptts_result* const* results, void* const* tags, int n);
+void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain);
+void cont_abort(ContEngine& e, int code, std::vector<void*>& done);
+
 // request dispatcher (dispatcher.cpp)
 struct Dispatcher;
 typedef int (*ExecFn)(void* user, int worker, const ptts_request* reqs, int32_t n, ptts_result* results, char* err, int32_t errlen);
-Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, void* user, int n_workers, int max_batch, int window_us, int queue_cap);
+struct DispatchCont { int on = 0, kv_capacity = 0, max_steps = 0, steps_per_group = 0; };   // ptts_dispatch_opts: continuous batching
+Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, void* user, int n_workers, int max_batch, int window_us, int queue_cap,
+                              const DispatchCont* cont = nullptr);
 void dispatcher_close(Dispatcher* d);
 int dispatcher_generate(Dispatcher* d, const ptts_request* req, ptts_result* res, std::string* err);
 void dispatcher_stats(Dispatcher* d, ptts_dispatch_stats* out);

@@ -748,7 +748,8 @@ def op_pcm16(samples) -> np.ndarray:
 
 
 class _DispatchOpts(C.Structure):
-    _fields_ = [("max_batch", C.c_int32), ("window_us", C.c_int32), ("queue_cap", C.c_int32), ("reserved", C.c_int32 * 5)]
+    _fields_ = [("max_batch", C.c_int32), ("window_us", C.c_int32), ("queue_cap", C.c_int32), ("continuous", C.c_int32), ("cont_kv_capacity", C.c_int32),
+                ("cont_max_steps", C.c_int32), ("cont_steps_per_group", C.c_int32), ("reserved", C.c_int32 * 1)]
 
 
 class _DispatchStats(C.Structure):
@@ -763,14 +764,16 @@ class Dispatcher:
     """The serving front of the runtime: `generate` blocks like Synthesize behind the reference's worker
     semaphore (internal/server/server.go:398-421); concurrent callers are coalesced into batched GenerateAudio passes."""
 
-    def __init__(self, models: Sequence[Model], max_batch: int = 0, window_us: int = 2000, queue_cap: int = 0, _custom_exec=None, _workers: int = 1):
+    def __init__(self, models: Sequence[Model], max_batch: int = 0, window_us: int = 2000, queue_cap: int = 0, _custom_exec=None, _workers: int = 1,
+                 continuous: bool = False, cont_kv_capacity: int = 0, cont_max_steps: int = 0, cont_steps_per_group: int = 0):
         L = lib()
         L.ptts_dispatcher_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(_DispatchOpts), C.POINTER(C.c_void_p)]
         L.ptts_dispatcher_create_custom.argtypes = [DISPATCH_EXEC, C.c_void_p, C.c_int32, C.POINTER(_DispatchOpts), C.POINTER(C.c_void_p)]
         L.ptts_dispatch_generate.argtypes = [C.c_void_p, C.POINTER(_Request), C.POINTER(_Result)]
         L.ptts_dispatcher_stats.argtypes = [C.c_void_p, C.POINTER(_DispatchStats)]
         L.ptts_dispatcher_close.argtypes = [C.c_void_p]
-        o = _DispatchOpts(max_batch=max_batch, window_us=window_us, queue_cap=queue_cap)
+        o = _DispatchOpts(max_batch=max_batch, window_us=window_us, queue_cap=queue_cap, continuous=1 if continuous else 0, cont_kv_capacity=cont_kv_capacity,
+                          cont_max_steps=cont_max_steps, cont_steps_per_group=cont_steps_per_group)
         h = C.c_void_p()
         self.models = list(models)
         if _custom_exec is not None:

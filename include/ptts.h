@@ -237,7 +237,14 @@ typedef struct ptts_dispatch_opts {
     int32_t window_us;    /* coalescing window, counted from the arrival of the oldest waiting request; stretched (to at most
                            * 4 windows) while requests keep arriving less than window_us / 4 apart */
     int32_t queue_cap;    /* <= 0: 4096; a full queue answers PTTS_ENOMEM */
-    int32_t reserved[5];
+    int32_t continuous;   /* 1: continuous batching -- one long-lived batch per model: between groups of AR steps, utterances that have
+                           * ended leave for the decoder and waiting requests take their slots (their prompts prefilled as one ragged
+                           * launch).  Requests with a step / PCM callback, lsd_steps > 1 or budgets beyond the two limits below run
+                           * batch-at-a-time while the engine is empty.  0: batch-at-a-time for everything */
+    int32_t cont_kv_capacity;      /* keys per slot (voice prefix + prompt + steps), <= 0: 512 (the reach of the one-burst step attention with a bf16 cache) */
+    int32_t cont_max_steps;        /* step budget per utterance, <= 0: 256 (EstimateMaxFrames of a 50-token chunk is 234) */
+    int32_t cont_steps_per_group;  /* AR steps between two looks at the slots, <= 0: 5 */
+    int32_t reserved[1];
 } ptts_dispatch_opts;
 typedef struct ptts_dispatch_stats {
     int64_t requests, batches, cancelled_waiting, max_queue_depth;
