@@ -165,6 +165,13 @@ def open_model(pkg, path, wl, rank, world, device):
     else:
         dist.broadcast(arena, src=0)      # the only collective of the whole job (weights, once)
     torch.cuda.synchronize()
+    # every rank holds the same bytes (checked, not assumed): a 64-bit sum of the arena, compared across ranks
+    pad = (-nbytes) % 8
+    cs = torch.sum(torch.nn.functional.pad(arena, (0, pad)).view(torch.int64)) if pad else torch.sum(arena.view(torch.int64))
+    sums = [torch.zeros_like(cs) for _ in range(world)]
+    dist.all_gather(sums, cs)
+    if len({int(x.item()) for x in sums}) != 1:
+        raise SystemExit(f"bench.py (rank {rank}): the weight arena differs between ranks after the broadcast")
     if rank != 0:
         model = pkg.Model.open_planned(plan, arena.data_ptr(), fill=False)
     return model, arena
@@ -174,6 +181,48 @@ def gen_cfgs(pkg, wl, n, voice, **kw):
     base = dict(temperature=0.0, eos_threshold=float("inf"), max_steps=wl["frames"], lsd_decode_steps=1, frames_after_eos=3, device_voice=voice)
     base.update(kw)
     return [pkg.RuntimeGenerateConfig(**base) for _ in range(n)]
+
+
+def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_client=2):
+    """BASELINE.json configs[3] names the serve-mode worker pool (internal/server/server.go:119-143,398-421): this rank's share of it is one
+    dispatcher over two engines of its GPU (one weight arena), fed by closed-loop clients that each synthesise 10-s utterances back to back
+    (64 per engine in flight).  Returns (audio seconds, wall seconds, p50 latency) of the timed rounds; an untimed round comes first."""
+    import threading
+    m2 = model.share()
+    for m in (model, m2):
+        m.set_use_graph(False)   # plain launches: the dispatcher's default, and no idle gap between replays when two engines interleave
+    disp = pkg.Dispatcher([model, m2], max_batch=wl["batch"], window_us=3000)
+    cfg = gen_cfgs(pkg, wl, 1, voice, pcm16=True)[0]
+    toks = [p.tolist() for p in prompts]
+    lat = []
+    lock = threading.Lock()
+
+    def client(i, n):
+        for k in range(n):
+            t0 = time.perf_counter()
+            r = disp.generate(toks[(i + k) % len(toks)], cfg)
+            with lock:
+                lat.append(time.perf_counter() - t0)
+            assert r.n_frames == wl["frames"]
+
+    def round_(n):
+        ts = [threading.Thread(target=client, args=(i, n)) for i in range(clients)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+
+    round_(1)
+    lat.clear()
+    sync(); barrier()
+    t0 = time.perf_counter()
+    round_(per_client)
+    sync()
+    dt = time.perf_counter() - t0
+    barrier()
+    st = disp.stats()
+    disp.close()
+    m2.close()
+    model.set_use_graph(True)
+    return clients * per_client * wl["frames"] * FRAME_SEC, dt, statistics.median(lat), st["mean_batch"]
 
 
 def run_workload(pkg, model, wl, prompts, voice, steps, warmup, barrier, sync, **cfg_kw):
@@ -507,6 +556,18 @@ def main():
         result["temperature_0p7"] = {"value": round(wl["batch"] * wl["frames"] * FRAME_SEC * args.steps / e3, 1), "unit": "x real-time",
                                      "ms_per_step": round(1e3 * e3 / args.steps, 3),
                                      "config": "same workload at temperature 0.7: N(0,1)*sqrt(T) per (request, step) drawn on the device (flow_lm.go:386-408)"}
+    if not args.no_two_engines and args.workload == "b64_10s_bf16":
+        # every rank, its own GPU: the serve-mode shape of configs[3] (per-GPU shard of the worker pool); aggregate = sum of the ranks' audio
+        # over the slowest rank's wall time, like `value`
+        try:
+            a_s, dt_s, p50_s, mb_s = serve_pass(pkg, model, wl, prompts, voice, barrier, sync)
+            dt_all = max_over_ranks(dt_s, world, dev)
+            result["serve_mode"] = {"value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
+                                    "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
+                                    "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 2 "
+                                              f"requests of {wl['frames']} frames, PCM16; {world} GPU(s), no exchange between them"}
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] serve-mode pass failed: {e}")
     if rank == 0:
         try:
             result["roofline"] = roofline_pass(pkg, model, wl, prompts, voice, traffic)

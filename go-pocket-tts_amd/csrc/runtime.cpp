@@ -1085,7 +1085,11 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     Batch& b = *m.cached_batch;
     batch_reset(b);
     {
-        std::vector<int32_t> v_ms(ms.begin(), ms.end()), v_fae((size_t)B);
+        // (a slot stops at most one frame past what the decoder's RoPE table reaches: generating that frame is what the reference reports as the
+        // error, mimi.go:498 -- for that utterance alone; the other utterances of the batch are unaffected)
+        const int dec_limit = ROPE_SEQ / d.up_stride;
+        std::vector<int32_t> v_ms((size_t)B), v_fae((size_t)B);
+        for (int i = 0; i < B; i++) v_ms[(size_t)i] = std::min(ms[(size_t)i], dec_limit + 1);
         std::vector<float> v_thr((size_t)B);
         for (int i = 0; i < B; i++) { v_fae[i] = reqs[idx[i]].frames_after_eos; v_thr[i] = reqs[idx[i]].eos_threshold; }
         h2d(b.st.max_steps, v_ms.data(), (size_t)B * 4, s);
@@ -1299,7 +1303,8 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     bool any_cancel_flag = false;
     for (int i = 0; i < B; i++) any_cancel_flag |= reqs[idx[i]].cancel != nullptr;
     const int gsteps = (use_graph && !any_cb && !any_cancel_flag && chunk > ms_max) ? env_gsteps : 1;
-    for (int step = 0; step < ms_max;) {
+    const int ms_loop = std::min(ms_max, t_limit + 1);
+    for (int step = 0; step < ms_loop;) {
         int n_cancel = 0;
         for (int i = 0; i < B; i++) {  // ctx.Err() check before every step (:156-159)
             const ptts_request& r = reqs[idx[i]];
@@ -1307,7 +1312,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             n_cancel += cancelled[i];
         }
         if (n_cancel == B) break;
-        const int n_now = (gsteps > 1 && step + gsteps <= ms_max) ? gsteps : 1;
+        const int n_now = (gsteps > 1 && step + gsteps <= ms_loop) ? gsteps : 1;
         enqueue_step(b, lsd, use_graph, n_now);
         step += n_now;
         steps_run = step;
@@ -1336,7 +1341,12 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     PTTS_HIP(hipStreamSynchronize(s));
     const std::vector<int32_t> nf(b.n_active_pinned + 1, b.n_active_pinned + 1 + B), es(b.n_active_pinned + 1 + B, b.n_active_pinned + 1 + 2 * B);
     int Tmax = 0;
-    for (int i = 0; i < B; i++) if (!cancelled[i]) Tmax = std::max(Tmax, nf[i]);
+    std::vector<char> overlong((size_t)B, 0);   // utterances that ran past the decoder's reach: failed one by one, like the reference's one GenerateAudio call
+    for (int i = 0; i < B; i++) {
+        overlong[(size_t)i] = !cancelled[i] && nf[i] > t_limit;
+        if (overlong[(size_t)i]) set_last_error(too_long(nf[i]).what());
+        if (!cancelled[i] && !overlong[(size_t)i]) Tmax = std::max(Tmax, nf[i]);
+    }
     if (Tmax > 0) {
         DevBuf* pcm_s16 = nullptr;   // PCM16 egress on the device (audio/wav_stream.go:43-54) for the requests that ask for it
         bool any_s16 = false;
@@ -1349,6 +1359,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         for (int i = b0; i < b1; i++) {
             ptts_result& r = res[idx[i]];
             if (cancelled[i]) { fail_req(r, PTTS_ECANCELLED); continue; }
+            if (overlong[(size_t)i]) { fail_req(r, PTTS_EINVAL); result_free(host_dst[(size_t)i]); host_dst[(size_t)i] = nullptr; continue; }
             r.n_frames = nf[i];
             r.eos_step = es[i];
             r.n_samples = (int64_t)nf[i] * spf;
@@ -1387,7 +1398,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             PcmRow* rows = b.rows_pinned;
             for (int i = 0; i < B; i++) rows[i] = PcmRow{nullptr, 0, 0};
             for (int i = 0; i < B; i++) {
-                if (cancelled[i]) continue;
+                if (cancelled[i] || overlong[(size_t)i]) continue;
                 const bool s16 = reqs[idx[i]].pcm_format == PTTS_PCM_S16;
                 const int64_t ns = (int64_t)nf[i] * spf;
                 host_dst[(size_t)i] = result_alloc((size_t)std::max<int64_t>(1, ns) * (s16 ? sizeof(int16_t) : sizeof(float)));
@@ -1423,7 +1434,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     } else {
         PTTS_HIP(hipStreamSynchronize(m.stream2));
         for (int32_t* p : stream_nf) (void)hipHostFree(p);
-        for (int i = 0; i < B; i++) fail_req(res[idx[i]], PTTS_ECANCELLED);
+        for (int i = 0; i < B; i++) fail_req(res[idx[i]], overlong[(size_t)i] ? PTTS_EINVAL : PTTS_ECANCELLED);
     }
     for (void* p : stream_host) result_free(p);   // buffers of cancelled / failed streaming requests
     unwind.armed = false;

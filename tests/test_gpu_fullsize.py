@@ -41,7 +41,8 @@ HEAD_BF16_LAT, HEAD_BF16_PCM = (1.4e-2, None), (1e-2, None)     # observed 1.4e-
 # free-running, whole length: GPU-vs-oracle error at step t over the running maximum of the reference's own AVX2-vs-scalar
 # difference up to t (both amplified by the model's dynamics at the same rate; the GPU's bf16 hi/lo operand split starts ~13x
 # above a pure summation-order change)
-ENVELOPE_FACTOR = 100.0   # observed 27
+ENVELOPE_FACTOR = 70.0    # observed 26.7 with round 2's kernels, 34.8 with round 3's (a one-ulp change of summation order moves it: the ratio of two
+                          # chaotic error curves); 2x the larger.  Deterministic per build: the same kernels give the same ratio on every box
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -839,3 +839,24 @@ def test_step_budget_beyond_the_decoder_table_fails_only_if_that_many_frames_are
     with pytest.raises(pkg.PttsError) as e:
         pkg.Runtime(gm).generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=600))
     assert "rope cos/sin sequence length too small" in str(e.value) and "mimi_decode" in str(e.value)
+    # ... and in a batch only the utterance that ran past the table fails (the reference fails that one GenerateAudio call, not its
+    # neighbours): it stops one frame past the table instead of running its whole budget, the others return their audio
+    others = [np.array([5, 6, 7], np.int64), np.array([9, 8], np.int64)]
+    cfgs = [pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=6, want_latents=True),
+            pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=600),
+            pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=4, want_latents=True)]
+    L = pkg.runtime.lib()
+    import ctypes as C
+    reqs, ress, keep = (pkg.runtime._Request * 3)(), (pkg.runtime._Result * 3)(), []
+    for i, t in enumerate([others[0], np.array(toks, np.int64), others[1]]):
+        gm._fill_request(reqs[i], t, cfgs[i], keep)
+    rc = L.ptts_generate(gm.h, reqs, 3, ress)
+    assert rc == 0 or "rope cos/sin" in L.ptts_last_error().decode()
+    assert [int(r.status) for r in ress] == [0, pkg.runtime.PTTS_EINVAL, 0] and "rope cos/sin sequence length too small" in L.ptts_last_error().decode()
+    for i, j in ((0, 0), (2, 1)):
+        want = gm.generate_batch([others[j]], [cfgs[i]])[0]
+        got_lat = np.ctypeslib.as_array(ress[i].latents, (ress[i].n_frames, 32)).copy()
+        assert ress[i].n_frames == cfgs[i].max_steps
+        parity(f"neighbour {i} of an over-long utterance", got_lat, want.latents, (1e-4, 5e-3))
+    for r in ress:
+        L.ptts_free_result(C.byref(r))
