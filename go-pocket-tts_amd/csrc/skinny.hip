@@ -141,7 +141,8 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     __builtin_amdgcn_sched_barrier(0);
     // The CU's vector-memory port serves its waves' requests in the order they were issued, across waves: without this barrier
     // wave 15's rows queue behind the weights of waves 0..14 (120 KB), and the prologue of the block is as late as its last wave.
-    __builtin_amdgcn_s_barrier();
+    // (a tile of a few rows -- the reference's own batch-1 case -- has nothing worth waiting for: its weights go out at once)
+    if (p_m - m0 > 4) __builtin_amdgcn_s_barrier();
     // ---- weights: everything this wave will multiply is requested now ----
     // Fragment-ordered copy (model.cpp add_tiled, zero-padded to 16 columns x 128 k): one contiguous 1-KiB burst per
     // wave-instruction.  The loads are unconditional (a tile / super-step that does not exist re-reads block 0 and is never

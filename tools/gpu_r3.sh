@@ -12,6 +12,8 @@ for step in "$@"; do
     tests) tools/gpu_tests.sh $tag; rc=$?; [ $rc -ne 0 ] && rc_all=$rc ;;
     quick) timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-b1 --no-traffic --no-two-engines --steps 8 > gpurun_out/${tag}_quick$sfx.json 2> gpurun_out/${tag}_quick$sfx.err; echo "quick$sfx rc=$?"
            python3 -c "import json;d=json.load(open('gpurun_out/${tag}_quick$sfx.json'));r=d['roofline'];print('quick$sfx', d['value'],d['ms_per_step'],r['avg_launch_us'],r.get('phases_ms'))" ;;
+    quickb1) timeout -k 10 300 python3 bench.py --workload b1_5s_f32 --no-cpu-baseline --no-b1 --no-traffic --no-two-engines --steps 12 --warmup 3 > gpurun_out/${tag}_quickb1$sfx.json 2> gpurun_out/${tag}_quickb1$sfx.err; echo "quickb1$sfx rc=$?"
+           python3 -c "import json;d=json.load(open('gpurun_out/${tag}_quickb1$sfx.json'));r=d['roofline'];print('quickb1$sfx', d['value'],d['ms_per_step'],r['avg_launch_us'],r.get('phases_ms'))" ;;
     stamps) timeout -k 10 200 python3 tools/step_stamps.py > gpurun_out/${tag}_stamps$sfx.txt 2>&1; echo "stamps$sfx rc=$?"; grep -c pro= gpurun_out/${tag}_stamps$sfx.txt ;;
     bench) timeout -k 10 900 python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err; echo "bench rc=$?"; tail -c 1200 gpurun_out/${tag}_bench.json; echo ;;
     prof) mkdir -p gpurun_out/${tag}_prof$sfx
