@@ -98,7 +98,9 @@ int    ptts_model_open_planned(ptts_plan* p, void* device_arena, int fill, ptts_
 /* The broadcast itself, for hosts that have no collective library of their own (the reference's Go server): rank 0 makes the id
  * (ncclGetUniqueId), hands the 128 bytes to the other processes over the channel that started them, then EVERY rank calls
  * ptts_rccl_broadcast on its arena (root = rank 0; one ncclCommInitRank + ncclBroadcast + ncclCommDestroy over RCCL / xGMI).
- * librccl is loaded on first use (PTTS_RCCL_LIB overrides the name). */
+ * librccl is loaded on first use (PTTS_RCCL_LIB overrides the name).
+ * STATUS: exercised with n_ranks == 1 only (tests/test_gpu_model.py); the two-rank test (tests/test_gpu_multirank.py) needs a box with
+ * two GPUs and has not run.  Compare a checksum of the arena across ranks after the hand-over (bench.py open_model does). */
 int    ptts_rccl_unique_id(uint8_t out[128]);
 int    ptts_rccl_broadcast(void* device_buf, size_t bytes, int32_t rank, int32_t n_ranks, const uint8_t id[128], int32_t device);
 /* host image of the arena (ptts_plan_arena_bytes() bytes), for hosts that upload / broadcast it themselves; needs no GPU */
