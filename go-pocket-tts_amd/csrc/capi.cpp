@@ -832,9 +832,14 @@ int ptts_debug_step_stamps(ptts_batch* hb, int32_t lsd_steps, uint64_t* out, int
 }
 
 // debug: time one many-row GEMM variant (2 = k_gemm2, 3 = k_gemm3) and compare it with the other one on pseudo-random data
-int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us, float* maxdiff) {
+int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi_flags, int32_t iters, float* avg_us, float* maxdiff) {
     return guard([&] {
         require_device();
+        // epi_flags: the epilogue form in the low byte; 0x100: RoPE on the first two thirds of the columns (positions restart every
+        // 2000 rows: the decoder's qkv projection); 0x200: the residual is read from the output buffer itself (the decoder's
+        // out_proj / linear2), 0x400: activations behind a prologue ELU, 0x800: a per-column scale
+        const int epi = epi_flags & 0xff;
+        const bool rope = epi_flags & 0x100, inplace = epi_flags & 0x200;
         const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
         std::vector<float> ha(na), hw(nw), hb((size_t)N);
         uint32_t st = 12345u;
@@ -842,27 +847,45 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         for (auto& x : ha) x = rnd();
         for (auto& x : hw) x = rnd() * 0.05f;
         for (auto& x : hb) x = rnd();
-        Tmp dA(na * 4), dW(nw * 4), dB((size_t)N * 4), dC(nc * 4), dC2(nc * 4), dR(nc * 4);
+        Tmp dA(na * 4), dW(nw * 4), dB((size_t)N * 4), dC(nc * 4), dC2(nc * 4), dR(nc * 4), dCos(2000 * 32 * 4), dSin(2000 * 32 * 4);
         up(dA.p, ha.data(), na * 4); up(dB.p, hb.data(), (size_t)N * 4);
         if (w_bf16) {
             std::vector<uint16_t> hw16(nw);
             for (size_t i = 0; i < nw; i++) { uint32_t u; memcpy(&u, &hw[i], 4); hw16[i] = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
             up(dW.p, hw16.data(), nw * 2);
         } else up(dW.p, hw.data(), nw * 4);
-        PTTS_HIP(hipMemset(dR.p, 0, nc * 4));
+        if (inplace) {   // a residual with content: the first nc values of the activations' generator, continued
+            std::vector<float> hr(nc);
+            for (auto& x : hr) x = rnd();
+            up(dR.p, hr.data(), nc * 4);
+        } else PTTS_HIP(hipMemset(dR.p, 0, nc * 4));
+        if (rope) {
+            std::vector<float> hc(2000 * 32), hs(2000 * 32);
+            for (size_t i = 0; i < hc.size(); i++) { const float ang = rnd() * 3.14159265f; hc[i] = std::cos(ang); hs[i] = std::sin(ang); }
+            up(dCos.p, hc.data(), hc.size() * 4); up(dSin.p, hs.data(), hs.size() * 4);
+        }
         GemmArgs g;
         g.A = dA.as<float>(); g.amap = RowMap{K, 0, 0};
         g.W = dW.p; g.w_bf16 = w_bf16; g.ldw = K; g.bias = dB.as<float>();
         g.C = dC.as<float>(); g.cmap = RowMap{N, 0, 0};
         g.R = dR.as<float>(); g.epi = epi;
         g.M = M; g.N = N; g.K = K;
-        if (!gemm2_supported(g) || !gemm3_supported(g)) throw Error(PTTS_EINVAL, "shape not supported");
-        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies)
+        if (epi_flags & 0x400) g.aop = AOP_ELU;
+        if (epi_flags & 0x800) g.scale = dB.as<float>();   // a per-column scale (the decoder's layer scale): the bias values serve
+        if (rope) {
+            g.rope_cos = dCos.as<float>(); g.rope_sin = dSin.as<float>(); g.rope_cols = N / 3 * 2; g.rope_hd = 64; g.rope_pos0 = 0; g.rope_rows_per_seg = 2000;
+            g.bias = nullptr;
+        }
+        if (!gemm3_supported(g)) throw Error(PTTS_EINVAL, "shape not supported");
+        // variant 2: k_gemm2, 3: k_gemm3 (30 + cfg: a forced shape), 40: whatever launch_gemm dispatches (k_gemm_wres where it applies),
+        // 50 + cfg: k_gemm5
         auto run = [&](int v, float* c) {
             GemmArgs h = g; h.C = c;
-            if (v == 40) launch_gemm(h, nullptr);
+            if (inplace) { PTTS_HIP(hipMemcpyAsync(c, dR.p, nc * 4, hipMemcpyDeviceToDevice, nullptr)); h.R = c; }
+            if (v == 40) { if (rope) { if (!launch_gemm_rope(h, nullptr)) throw Error(PTTS_EINVAL, "no RoPE epilogue for this shape"); } else launch_gemm(h, nullptr); }
+            else if (v >= 50) { if (!gemm5_supported(h)) throw Error(PTTS_EINVAL, "shape not supported by k_gemm5"); g_gemm5_cfg = v - 50; launch_gemm5(h, nullptr); g_gemm5_cfg = 0; }
             else if (v >= 3) { g_gemm3_cfg = v >= 30 ? v - 30 : 0; launch_gemm3(h, nullptr); g_gemm3_cfg = 0; }
-            else launch_gemm2(h, nullptr);
+            else { if (!gemm2_supported(h)) throw Error(PTTS_EINVAL, "shape not supported by k_gemm2"); launch_gemm2(h, nullptr); }
         };
         hipEvent_t e0, e1;
         PTTS_HIP(hipEventCreate(&e0)); PTTS_HIP(hipEventCreate(&e1));
@@ -877,13 +900,32 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         *avg_us = ms * 1e3f / (float)iters;
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         *maxdiff = -1.0f;
-        if (nc <= ((size_t)64 << 20)) {
-            run(variant >= 40 ? 3 : (variant >= 3 ? 2 : 3), dC2.as<float>());   // the dispatcher's choice is held against k_gemm3 (same k order: equal bits)
+        if (nc <= ((size_t)200 << 20)) {
+            // against k_gemm3 (k_gemm2 for k_gemm3 itself): the same k order, so equal bits are expected; and the variant against itself,
+            // three more runs (a race shows as a difference between runs)
+            run(variant >= 40 ? 3 : (variant >= 3 ? 2 : 3), dC2.as<float>());
             PTTS_HIP(hipDeviceSynchronize());
             std::vector<float> c1(nc), c2(nc);
             down(c1.data(), dC.p, nc * 4); down(c2.data(), dC2.p, nc * 4);
             float md = 0;
-            for (size_t i = 0; i < nc; i++) { float d = std::fabs(c1[i] - c2[i]); if (!(d <= md)) md = d; }
+            size_t nbad = 0;
+            for (size_t i = 0; i < nc; i++) {
+                float d = std::fabs(c1[i] - c2[i]);
+                if (!(d <= md)) md = d;
+                if (d != 0 && nbad++ < 12) fprintf(stderr, "ptts_debug_gemm: variant %d vs reference at row %zu column %zu: %.9g vs %.9g\n", variant, i / N, i % N, c1[i], c2[i]);
+            }
+            if (nbad) fprintf(stderr, "ptts_debug_gemm: %zu of %zu values differ from the reference kernel's\n", nbad, nc);
+            for (int rep = 0; rep < 3; rep++) {
+                run(variant, dC2.as<float>());
+                PTTS_HIP(hipDeviceSynchronize());
+                down(c2.data(), dC2.p, nc * 4);
+                if (memcmp(c1.data(), c2.data(), nc * 4) != 0) {
+                    size_t bad = 0, first = nc;
+                    for (size_t i = 0; i < nc; i++) if (memcmp(&c1[i], &c2[i], 4) != 0) { if (first == nc) first = i; bad++; }
+                    fprintf(stderr, "ptts_debug_gemm: variant %d differs from itself between runs: %zu of %zu values, first at row %zu column %zu\n", variant, bad, nc, first / N, first % N);
+                    md = 1e30f;
+                }
+            }
             *maxdiff = md;
         }
     });

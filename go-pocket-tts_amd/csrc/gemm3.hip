@@ -188,8 +188,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
                 const float2 cs = *reinterpret_cast<const float2*>(a.rope_cos + (int64_t)pos * half + j);
                 const float2 sn = *reinterpret_cast<const float2*>(a.rope_sin + (int64_t)pos * half + j);
                 const float x0 = v.x, x1 = v.y, x2 = v.z, x3 = v.w;
-                v.x = x0 * cs.x - x1 * sn.x; v.y = x0 * sn.x + x1 * cs.x;
-                v.z = x2 * cs.y - x3 * sn.y; v.w = x2 * sn.y + x3 * cs.y;
+                {
+#pragma clang fp contract(off)
+                    // rounded product by product (the reference's x*c - y*s, rope.go:81-105), the same bits as k_gemm5's epilogue
+                    v.x = x0 * cs.x - x1 * sn.x; v.y = x0 * sn.x + x1 * cs.x;
+                    v.z = x2 * cs.y - x3 * sn.y; v.w = x2 * sn.y + x3 * cs.y;
+                }
             }
             const int64_t co = ro + col;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -66,6 +66,9 @@ void launch_gemm2(const GemmArgs& a, hipStream_t stream);
 bool gemm3_supported(const GemmArgs& a);   // direct-to-register activations, 256-row blocks (gemm3.hip)
 void launch_gemm3(const GemmArgs& a, hipStream_t stream);
 extern thread_local int g_gemm3_cfg;
+bool gemm5_supported(const GemmArgs& a);   // gemm3's data movement without its conditional loads, swizzled weight image, batched epilogue (gemm5.hip)
+void launch_gemm5(const GemmArgs& a, hipStream_t stream);
+extern thread_local int g_gemm5_cfg;
 
 // Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.

@@ -143,6 +143,8 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
 }
 
 bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream) {
+    static const int g5 = [] { const char* e = getenv("PTTS_GEMM5"); return e ? atoi(e) : 1; }();   // A/B measurement
+    if (g5 && gemm5_supported(a)) { launch_gemm5(a, stream); return true; }
     if (!gemm3_supported(a)) return false;
     launch_gemm3(a, stream);
     return true;
@@ -156,6 +158,8 @@ void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 64 && a.Wt && skinny_supported(a, 1)) { launch_skinny(a, SkinnyFuse{}, 1, nullptr, stream); return; }
     static const int wres = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 1; }();   // A/B measurement
     if (wres && force != 2 && gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
+    static const int g5 = [] { const char* e = getenv("PTTS_GEMM5"); return e ? atoi(e) : 1; }();   // A/B measurement
+    if (g5 && force != 2 && gemm5_supported(a)) { launch_gemm5(a, stream); return; }
     if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     note_launch("k_gemm");
@@ -286,8 +290,11 @@ __global__ void k_rope_rows(float* x, RowMap xmap, int col0, int heads, int hd, 
     float* v = x + row_off(xmap, r) + col0 + h * hd + 2 * j;
     float a = v[0], b = v[1];
     float c = cos_t[(int64_t)p * half + j], s = sin_t[(int64_t)p * half + j];
-    v[0] = a * c - b * s;
-    v[1] = a * s + b * c;
+    {
+#pragma clang fp contract(off)
+        v[0] = a * c - b * s;   // rounded product by product (the GEMM epilogues' form: gemm3.hip / gemm5.hip)
+        v[1] = a * s + b * c;
+    }
 }
 void launch_rope_rows(float* x, RowMap xmap, int col0, int heads, int hd, const int32_t* pos, int pos_base, int rows_per_seg,
                       int rows, const float* cos_t, const float* sin_t, hipStream_t stream) {

@@ -13,7 +13,8 @@ scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25     # fraction of the 
 variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2, 3]
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 R = 128000
-shapes = [("qkv", R, 1536, 512, 0), ("out_proj", R, 512, 512, 4), ("ffn1", R, 2048, 512, 1), ("ffn2", R, 512, 2048, 4),
+# epilogue codes: +0x100 RoPE, +0x200 residual read from the output buffer, +0x400 prologue ELU (capi.cpp ptts_debug_gemm)
+shapes = [("qkv", R, 1536, 512, 0), ("qkv_rope", R, 1536, 512, 0x100), ("out_proj_ip", R, 512, 512, 0x205), ("out_proj_ls", R, 512, 512, 0xa05), ("ffn2_ip", R, 512, 2048, 0x205), ("rb1_0_elu", 6 * R, 128, 768, 0x403), ("rb2_0_re", 6 * R, 256, 128, 8), ("out_proj", R, 512, 512, 4), ("ffn1", R, 2048, 512, 1), ("ffn2", R, 512, 2048, 4),
           ("init_conv", R, 512, 3584, 3), ("up1", R, 1536, 1024, 0), ("rb1_0", 6 * R, 128, 768, 3), ("rb2_0", 6 * R, 256, 128, 4),
           ("up2", 6 * R, 640, 512, 0), ("rb1_1", 30 * R, 64, 384, 3), ("rb2_1", 30 * R, 128, 64, 4), ("up3", 30 * R, 256, 256, 0),
           ("rb1_2", 120 * R, 32, 192, 3), ("rb2_2", 120 * R, 64, 32, 4)]
@@ -32,6 +33,6 @@ for bf16 in (1,):
                 line += f" | v{v} unsupported: {L.ptts_last_error().decode()}"
                 continue
             fl = 2.0 * M * N * K
-            by = 4.0 * M * (K + N * (2 if epi >= 4 else 1))
+            by = 4.0 * M * (K + N * (2 if (epi & 0xff) >= 4 else 1))
             line += f" | v{v} {us.value:9.1f} us {fl/us.value/1e6:7.1f} TF {by/us.value/1e3:7.0f} GB/s diff {md.value:.2e}"
         print(line, flush=True)
