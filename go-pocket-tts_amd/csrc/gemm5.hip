@@ -264,7 +264,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bool gemm5_supported(const GemmArgs& a) {
     const bool res = a.epi >= EPI_RESADD;
     const bool epi_ok = a.epi == EPI_NONE || a.epi == EPI_GELU || a.epi == EPI_ELU || a.epi == EPI_RESADD || a.epi == EPI_SCALE_RESADD || a.epi == EPI_RESADD_ELU;
-    return a.w_bf16 && epi_ok && a.M >= 16384 && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && (a.N < 256 || a.N % 256 == 0) && !a.kslice && !a.tail &&
+    return a.w_bf16 && epi_ok && a.M >= 16384 && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && !a.kslice && !a.tail &&
            aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0 && a.ldw % 8 == 0 && aligned16(a.W) && (int64_t)a.N * a.ldw * 2 >= (int64_t)a.N * 4 &&
            aligned16(a.C) && a.cmap.ld % 4 == 0 && a.cmap.batch_stride % 4 == 0 && (!a.bias || aligned16(a.bias)) && (!a.scale || aligned16(a.scale)) &&
            (!res || aligned16(a.R)) && (!a.rope_cos || (a.rope_hd == 64 && a.rope_cols % 64 == 0 && a.epi == EPI_NONE));
@@ -281,7 +281,7 @@ static void launch5_cfg(const GemmArgs& a, hipStream_t stream) {
 void launch_gemm5(const GemmArgs& a, hipStream_t stream) {
     note_launch(a.rope_cos ? "k_gemm5+rope" : "k_gemm5");
     const int cfg = g_gemm5_cfg;
-    const bool wide = a.N >= 256;
+    const bool wide = a.N % 256 == 0;   // (N = 640: 128-column tiles)
     switch (cfg) {
         case 1: launch5_cfg<256, 8>(a, stream); return;
         case 2: launch5_cfg<256, 4>(a, stream); return;

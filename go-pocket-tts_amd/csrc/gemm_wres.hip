@@ -34,6 +34,10 @@ __device__ __forceinline__ void split2w(float a, float b, unsigned& hi, unsigned
     lo = *reinterpret_cast<unsigned*>(&l);
 }
 
+// chunk c (of the four 16-byte chunks of a column's 32 k) is stored at c ^ fw(column): with it the 16 lanes of each group a
+// ds_read_b128 is served in hit 16 different bank slots (gemm5.hip has the derivation; the plain layout was a 2-way conflict)
+__device__ __forceinline__ int wres_fw(int col) { return ((col >> 3) & 1) * 3; }
+
 union FragW {
     bf16x8 v;
     uint4 q;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a, int ntiles
             const int n = pc / PPR, kk = pc % PPR;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (n0 + n < a.N && kk * 8 < a.K) u = *reinterpret_cast<const uint4*>((const char*)a.W + ((int64_t)(n0 + n) * a.ldw + kk * 8) * 2);
-            *reinterpret_cast<uint4*>(Wl + (kk >> 2) * (WR_N * 64) + n * 64 + (kk & 3) * 16) = u;
+            *reinterpret_cast<uint4*>(Wl + (kk >> 2) * (WR_N * 64) + n * 64 + (((kk & 3) ^ wres_fw(n)) << 4)) = u;
         }
     }
     if (tid < WR_N) Bl[tid] = (a.bias && n0 + tid < a.N) ? a.bias[n0 + tid] : 0.0f;
@@ -76,21 +80,27 @@ __global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a, int ntiles
     const int nsteps = a.K >> 5;                      // K % 32 == 0 (host)
     const int total = mine * nsteps;
 
-    // the wave's rows, one 32-k step at a time: lane = row r16 (two 16-row tiles), k group g -> two float4 (8 k)
+    // the wave's rows, one 32-k step at a time: lane = row r16 (two 16-row tiles), k group g -> two float4 (8 k).  The ring is
+    // refilled in order, so the (panel, step) of the next request just advances: no division per request.
     float4 av[WR_RING][2][2];
-    auto a_load = [&](int q, float4 (&dst)[2][2]) {
-        const int pj = q / nsteps, i = q - pj * nsteps;
-        const int m0 = (p0 + pj * stride) << 5;
+    int lp = 0, li = 0;                               // panel ordinal and step of the next request
+    const float* lrow[2];
+    auto l_rows = [&]() {
+        const int m0 = (p0 + lp * stride) << 5;
+#pragma unroll
+        for (int t = 0; t < 2; t++) lrow[t] = a.A + row_off(a.amap, min(m0 + t * 16 + r16, a.M - 1)) + g * 8;
+    };
+    l_rows();
+    auto a_load = [&](float4 (&dst)[2][2]) {
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            const float* ap = a.A + row_off(a.amap, min(m0 + t * 16 + r16, a.M - 1)) + g * 8 + i * 32;
-            dst[t][0] = *reinterpret_cast<const float4*>(ap);
-            dst[t][1] = *reinterpret_cast<const float4*>(ap + 4);
+            dst[t][0] = *reinterpret_cast<const float4*>(lrow[t] + li * 32);
+            dst[t][1] = *reinterpret_cast<const float4*>(lrow[t] + li * 32 + 4);
         }
+        if (++li == nsteps) { li = 0; lp = min(lp + 1, mine - 1); l_rows(); }   // (past the last panel: its rows again, never used)
     };
 #pragma unroll
-    for (int r = 0; r < WR_RING; r++)
-        if (r < total) a_load(r, av[r]);
+    for (int r = 0; r < WR_RING; r++) a_load(av[r]);
 
     f32x4 acc[2][NT];
 #pragma unroll
@@ -113,18 +123,24 @@ __global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a, int ntiles
                     split2w(x1.x, x1.y, ah[t].q.z, al[t].q.z);
                     split2w(x1.z, x1.w, ah[t].q.w, al[t].q.w);
                 }
-                if (q + WR_RING < total) a_load(q + WR_RING, av[r]);
-                const unsigned char* wb = Wl + step * (WR_N * 64) + r16 * 64 + g * 16;
+                a_load(av[r]);                            // unconditional (no load behind a branch: the compiler would drain the ring there)
+                __builtin_amdgcn_sched_barrier(0);
+                const unsigned char* wb = Wl + step * (WR_N * 64) + r16 * 64 + ((g ^ wres_fw(r16)) << 4);
+                FragW wh[2];                              // fragment n + 1 is requested before fragment n is multiplied
+                wh[0].q = *reinterpret_cast<const uint4*>(wb);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
 #pragma unroll
                 for (int n = 0; n < NT; n++) {
-                    FragW wh;
-                    wh.q = *reinterpret_cast<const uint4*>(wb + n * 1024);
+                    if (n + 1 < NT) wh[(n + 1) & 1].q = *reinterpret_cast<const uint4*>(wb + (n + 1) * 1024);
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, ah[t].v, acc[t][n], 0, 0, 0);
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, al[t].v, acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n & 1].v, ah[t].v, acc[t][n], 0, 0, 0);
+                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n & 1].v, al[t].v, acc[t][n], 0, 0, 0);
                     }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
                 if (++step == nsteps) {               // the panel is complete: bias, epilogue, store, start over
                     const int m0 = (p0 + pj * stride) << 5;
 #pragma unroll

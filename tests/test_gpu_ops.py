@@ -200,3 +200,33 @@ def test_weights_resident_gemm_equals_the_tile_gemm(pkg, shape):
     rc = L.ptts_debug_gemm(M, N, K, 1, 40, epi, 1, C.byref(us), C.byref(md))
     assert rc == 0, L.ptts_last_error().decode()
     assert md.value == 0.0, (shape, md.value)
+
+
+@pytest.mark.parametrize("shape", [(16384, 1536, 512, 0x100), (16640, 1536, 512, 0x000), (16384, 512, 512, 0x204), (16384, 512, 2048, 0x204), (16384, 512, 3584, 0x003),
+                                   (16384, 1536, 1024, 0x000), (49152, 128, 768, 0x403), (49152, 256, 128, 0x008), (16384, 2048, 512, 0x001), (16400, 256, 64, 0x000)])
+def test_many_row_gemm5_equals_gemm3_bit_for_bit_and_itself_run_to_run(pkg, shape):
+    """k_gemm5 (bf16 weights, >= 16384 rows: the decoder's deep GEMMs at the benchmark's batch) keeps k_gemm3's k order, so every form the
+    decoder uses must give k_gemm3's bits: the qkv projection with the RoPE epilogue (positions restarting every 2000 rows), plain bias,
+    a residual read from the output buffer itself (out_proj / linear2 update the stream in place), ELU (first convolution), a prologue
+    ELU (the residual block's first convolution: 128 columns), residual + ELU, GELU, a row count that is no multiple of the tile and a
+    single weight chunk (K = 64).  The debug entry also runs the variant three more times and compares bits (a race would show)."""
+    import ctypes as C
+    M, N, K, epi = shape
+    L = pkg.runtime.lib()
+    L.ptts_debug_gemm.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 2
+    us, md = C.c_float(0), C.c_float(-1)
+    rc = L.ptts_debug_gemm(M, N, K, 1, 50, epi, 1, C.byref(us), C.byref(md))
+    assert rc == 0, L.ptts_last_error().decode()
+    assert md.value == 0.0, (shape, md.value)
+
+
+def test_many_row_gemm5_layer_scale_epilogue_rounds_like_the_reference(pkg):
+    """residual + scale * (sums): k_gemm5 rounds the product and the sum one by one (the reference's r + s*v on amd64, mimi.go:275-285),
+    k_gemm3 lets the compiler fuse them: the two may differ in the last bit, not more."""
+    import ctypes as C
+    L = pkg.runtime.lib()
+    L.ptts_debug_gemm.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 2
+    us, md = C.c_float(0), C.c_float(-1)
+    rc = L.ptts_debug_gemm(16384, 512, 512, 1, 50, 0xa05, 1, C.byref(us), C.byref(md))
+    assert rc == 0, L.ptts_last_error().decode()
+    assert 0.0 <= md.value <= 5e-7, md.value
