@@ -198,6 +198,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
             const int64_t co = ro + col;
             float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
             if (a.epi >= EPI_RESADD) r = *reinterpret_cast<const float4*>(a.R + co);
+            {
+#pragma clang fp contract(off)
+            // one rounding per operation, like k_gemm5's epilogue and like the reference (r + s*v, r + alpha*v on amd64): with contraction the
+            // same row could get different last bits in different kernels
             switch (a.epi) {
                 case EPI_NONE: break;
                 case EPI_GELU: v.x = gelu1(v.x); v.y = gelu1(v.y); v.z = gelu1(v.z); v.w = gelu1(v.w); break;
@@ -222,6 +226,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm3(GemmArgs a) {
                 }
                 case EPI_RESADD_ELU: v.x = elu_fast(r.x + v.x); v.y = elu_fast(r.y + v.y); v.z = elu_fast(r.z + v.z); v.w = elu_fast(r.w + v.w); break;
                 case EPI_AXPY: v.x = r.x + a.alpha * v.x; v.y = r.y + a.alpha * v.y; v.z = r.z + a.alpha * v.z; v.w = r.w + a.alpha * v.w; break;
+            }
             }
             *reinterpret_cast<float4*>(a.C + co) = v;
         }

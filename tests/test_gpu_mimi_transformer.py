@@ -148,3 +148,21 @@ def test_wide_batch_is_bit_reproducible_and_slot_symmetric(pkg, mimi_full):
             assert np.array_equal(xf[i], xf[31 - i]), (dtype, r, i)
             assert np.array_equal(pcm[i], pcm[31 - i]), (dtype, r, i)
         assert np.array_equal(xf, runs[0][2]) and np.array_equal(pcm, runs[0][0]), (dtype, r)
+
+
+def test_wide_batch_equals_the_single_utterance_path_bit_for_bit(pkg, mimi_full):
+    """16 utterances x 64 frames (16384 rows: k_gemm5 / k_gemm_wres with bf16 weights) against one utterance alone (1024 rows: k_gemm3):
+    the many-row kernels keep one k order, the same bf16 hi + lo halves and the same epilogue rounding (no contraction), so the
+    transformer's output must be the same BITS whatever the batch -- the property the slot-symmetry test needs at full size, held here
+    across kernels."""
+    dtype, om, gm = mimi_full
+    rng = np.random.default_rng(11)
+    x = lat(rng, 16, 64)
+    pkg.runtime.launch_counts(True)
+    _, _, xf = gm.decode_stages(x)
+    counts = pkg.runtime.launch_counts(False)
+    if dtype == "BF16":
+        assert counts.get("k_gemm5+rope", 0) == 2 and counts.get("k_gemm_wres<128,512>", 0) >= 2, counts
+    for u in (0, 9, 15):
+        _, _, one = gm.decode_stages(x[u:u + 1])
+        assert np.array_equal(xf[u], one[0]), (u, float(np.abs(xf[u] - one[0]).max()))
