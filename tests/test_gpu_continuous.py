@@ -82,27 +82,29 @@ def test_every_caller_gets_its_stand_alone_audio_with_slots_refilled_on_the_way(
         cfgs.append(pkg.RuntimeGenerateConfig(**kw))
     want = [gm.generate_batch([prompts[i]], [cfgs[i]])[0] for i in range(n)]
     d = pkg.Dispatcher([gm], max_batch=4, window_us=2000, continuous=True, cont_kv_capacity=64, cont_max_steps=32, cont_steps_per_group=3)
-    got, errs = run_clients(d, prompts, cfgs)
-    assert not any(errs), errs
-    st = d.stats()
-    assert st["requests"] == n and st["batches"] >= n // 4, st      # "batches" counts admissions here: 24 requests cannot fit 4 slots in fewer than 6
-    for i in range(n):
-        assert got[i].n_frames == want[i].n_frames == steps[i] and got[i].eos_step == -1
-        parity(f"continuous latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
-        if cfgs[i].pcm16:
-            assert got[i].pcm.dtype == np.int16 and np.abs(got[i].pcm.astype(np.int32) - want[i].pcm.astype(np.int32)).max() <= 2
-        else:
-            parity(f"continuous pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
-    for i in (0, 1, 2, 3):   # and against the reference's arithmetic: no voice, device voice, host voice state, voice embedding
-        kw = {}
-        if i % 6 in (1, 2):
-            kw["voice_state"] = voice_mods
-        if i % 6 == 3:
-            kw["voice_emb"] = ve[0]
-        ref = om.generate(prompts[i], max_steps=steps[i], eos_threshold=1e30, frames_after_eos=3, **kw)
-        parity(f"continuous latents[{i}] vs oracle", got[i].latents, ref["latents"], (2.5e-4, 5e-2))
-        parity(f"continuous pcm[{i}] vs oracle", got[i].pcm, ref["pcm"], (3e-4, 1e-1))
-    d.close()
+    try:
+        got, errs = run_clients(d, prompts, cfgs)
+        assert not any(errs), errs
+        st = d.stats()
+        assert st["requests"] == n and st["batches"] >= n // 4, st      # "batches" counts admissions here: 24 requests cannot fit 4 slots in fewer than 6
+        for i in range(n):
+            assert got[i].n_frames == want[i].n_frames == steps[i] and got[i].eos_step == -1
+            parity(f"continuous latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
+            if cfgs[i].pcm16:
+                assert got[i].pcm.dtype == np.int16 and np.abs(got[i].pcm.astype(np.int32) - want[i].pcm.astype(np.int32)).max() <= 2
+            else:
+                parity(f"continuous pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
+        for i in (0, 1, 2, 3):   # and against the reference's arithmetic: no voice, device voice, host voice state, voice embedding
+            kw = {}
+            if i % 6 in (1, 2):
+                kw["voice_state"] = voice_mods
+            if i % 6 == 3:
+                kw["voice_emb"] = ve[0]
+            ref = om.generate(prompts[i], max_steps=steps[i], eos_threshold=1e30, frames_after_eos=3, **kw)
+            parity(f"continuous latents[{i}] vs oracle", got[i].latents, ref["latents"], (2.5e-4, 5e-2))
+            parity(f"continuous pcm[{i}] vs oracle", got[i].pcm, ref["pcm"], (3e-4, 1e-1))
+    finally:
+        d.close()
     dv.close()
     gm.set_use_graph(False)
 
@@ -133,14 +135,16 @@ def test_eos_frees_a_slot_and_the_tail_frames_are_kept(pkg, tiny):
         cfgs.append(c)
         want.append(w)
     d = pkg.Dispatcher([gm], max_batch=3, window_us=1000, continuous=True, cont_kv_capacity=64, cont_max_steps=16, cont_steps_per_group=2)
-    got, errs = run_clients(d, prompts, cfgs, stagger_s=0.002)
-    assert not any(errs), errs
-    assert len({w.n_frames for w in want}) > 1                # the lengths do differ
-    for i in range(n):
-        assert (got[i].n_frames, got[i].eos_step) == (want[i].n_frames, want[i].eos_step), i
-        parity(f"continuous (EOS) latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
-        parity(f"continuous (EOS) pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
-    d.close()
+    try:
+        got, errs = run_clients(d, prompts, cfgs, stagger_s=0.002)
+        assert not any(errs), errs
+        assert len({w.n_frames for w in want}) > 1                # the lengths do differ
+        for i in range(n):
+            assert (got[i].n_frames, got[i].eos_step) == (want[i].n_frames, want[i].eos_step), i
+            parity(f"continuous (EOS) latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
+            parity(f"continuous (EOS) pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
+    finally:
+        d.close()
 
 
 def test_cancellation_callbacks_and_oversized_requests(pkg, tiny):
@@ -164,15 +168,17 @@ def test_cancellation_callbacks_and_oversized_requests(pkg, tiny):
     want = [None] + [gm.generate_batch([prompts[i]], [pkg.RuntimeGenerateConfig(max_steps=cfgs[i].max_steps, eos_threshold=1e30, want_latents=True,
                                                                                 lsd_decode_steps=cfgs[i].lsd_decode_steps)])[0] for i in range(1, 6)]
     d = pkg.Dispatcher([gm], max_batch=2, window_us=500, continuous=True, cont_kv_capacity=576, cont_max_steps=512, cont_steps_per_group=2)
-    canceller = threading.Timer(0.03, lambda: flag.__setitem__(0, 1))
-    canceller.start()
-    got, errs = run_clients(d, prompts, cfgs)
-    canceller.join()
-    assert isinstance(errs[0], pkg.Cancelled), errs[0]
-    assert not any(errs[1:]), errs
-    assert seen == [(s, 4) for s in range(1, 5)]
-    for i in range(1, 6):
-        assert got[i].n_frames == want[i].n_frames
-        parity(f"continuous mixed paths latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
-        parity(f"continuous mixed paths pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
-    d.close()
+    try:
+        canceller = threading.Timer(0.03, lambda: flag.__setitem__(0, 1))
+        canceller.start()
+        got, errs = run_clients(d, prompts, cfgs)
+        canceller.join()
+        assert isinstance(errs[0], pkg.Cancelled), errs[0]
+        assert not any(errs[1:]), errs
+        assert seen == [(s, 4) for s in range(1, 5)]
+        for i in range(1, 6):
+            assert got[i].n_frames == want[i].n_frames
+            parity(f"continuous mixed paths latents[{i}]", got[i].latents, want[i].latents, (1e-4, 5e-3))
+            parity(f"continuous mixed paths pcm[{i}]", got[i].pcm, want[i].pcm, (1e-4, 5e-2))
+    finally:
+        d.close()
