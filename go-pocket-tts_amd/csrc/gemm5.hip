@@ -1,6 +1,6 @@
-// gemm5.hip -- the many-row GEMM of the Mimi decoder, third generation (bf16 weights, M >= 16384 rows: the decoder
-// transformer's linears, the first SEANet convolution and transposed convolution, the wide residual block; mimi.go:719-789,
-// conv1d.go:20-83, convtranspose1d.go:73-148).
+// gemm5.hip -- the many-row GEMM, third generation (bf16 weights, M >= 1024 rows: the decoder transformer's linears, the first
+// SEANet convolution and transposed convolution, the wide residual block -- mimi.go:719-789, conv1d.go:20-83,
+// convtranspose1d.go:73-148 -- and the prompt prefill's projections, flow_transformer.go:749-771, in 128 x 128 tiles).
 //
 // Data movement and numerics are k_gemm3's (gemm3.hip): every wave loads its own 32 rows of f32 activations in full 128-byte
 // lines straight into registers, splits them into bf16 hi + lo and multiplies both by the bf16 weights
@@ -14,6 +14,7 @@
 //   * the weight image in LDS is XOR-swizzled for the lane groups gfx950 serves a ds_read_b128 in (every fragment read was a
 //     2-way bank conflict in k_gemm3's layout, and the fragment reads are half of the LDS port's time at full MFMA rate);
 //   * the prologue ELU of a consumer (the residual blocks' first convolution) is a template parameter, not a branch in the loop.
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -264,7 +265,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bool gemm5_supported(const GemmArgs& a) {
     const bool res = a.epi >= EPI_RESADD;
     const bool epi_ok = a.epi == EPI_NONE || a.epi == EPI_GELU || a.epi == EPI_ELU || a.epi == EPI_RESADD || a.epi == EPI_SCALE_RESADD || a.epi == EPI_RESADD_ELU;
-    return a.w_bf16 && epi_ok && a.M >= 16384 && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && !a.kslice && !a.tail &&
+    static const int min_m = [] { const char* e = getenv("PTTS_GEMM5_MIN_M"); return e ? atoi(e) : 1024; }();   // A/B measurement (16384: the decoder at many rows only)
+    return a.w_bf16 && epi_ok && a.M >= min_m && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && !a.kslice && !a.tail &&
            aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0 && a.ldw % 8 == 0 && aligned16(a.W) && (int64_t)a.N * a.ldw * 2 >= (int64_t)a.N * 4 &&
            aligned16(a.C) && a.cmap.ld % 4 == 0 && a.cmap.batch_stride % 4 == 0 && (!a.bias || aligned16(a.bias)) && (!a.scale || aligned16(a.scale)) &&
            (!res || aligned16(a.R)) && (!a.rope_cos || (a.rope_hd == 64 && a.rope_cols % 64 == 0 && a.epi == EPI_NONE));
@@ -298,7 +300,8 @@ void launch_gemm5(const GemmArgs& a, hipStream_t stream) {
 #endif
         default: break;
     }
-    if (wide) launch5_cfg<256, 8>(a, stream);
+    if (a.M < 16384) launch5_cfg<128, 4>(a, stream);     // few row panels (the prompt prefill): 128 x 128 tiles, two blocks per CU
+    else if (wide) launch5_cfg<256, 8>(a, stream);
     else launch5_cfg<128, 8>(a, stream);
 }
 
