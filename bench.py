@@ -243,7 +243,7 @@ def run_workload(pkg, model, wl, prompts, voice, steps, warmup, barrier, sync, *
     log("[bench] per-step ms: " + " ".join(f"{1e3*x:.1f}" for x in lat))
     frames = sum(o.n_frames for o in out)
     assert all(o.n_frames == wl["frames"] and o.pcm.shape[0] == wl["frames"] * 1920 for o in out)
-    assert all(np.isfinite(o.pcm).all() for o in out[:2])
+    assert os.environ.get("PTTS_PROBE_GARBAGE") or all(np.isfinite(o.pcm).all() for o in out[:2])   # (ablation builds of tools/probes feed garbage on purpose: timing only)
     return elapsed, lat, frames
 
 
