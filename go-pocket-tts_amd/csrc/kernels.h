@@ -223,9 +223,16 @@ struct ResArgs {
     const void* wf_hi = nullptr; const void* wf_lo = nullptr; const float* bf = nullptr;  // final conv as a one-column fragment-ordered matrix (hi + lo planes), bias [1]
     int B = 0, L = 0, t0 = 0, t1 = 0;
     int C = 0, H = 0, k1 = 0, k2 = 0, kf = 0, w_bf16 = 0, final_conv = 0;
+    // k_resblock_up (resblock_up.hip): the transposed convolution in front of the block computed in the same kernel -- u is then not read
+    // but made from xin, the previous block's rows [B][x_pad + x_L][CI] (x_L = L / up_stride), with the fragment-ordered [stride*C][2*CI]
+    // weights wup (bf16) and the bias bup [C]
+    int fuse_up = 0; const float* xin = nullptr; int64_t x_bs = 0; int x_pad = 0, x_L = 0, CI = 0, up_stride = 0;
+    const void* wup = nullptr; const float* bup = nullptr;
 };
 bool resblock_supported(const ResArgs& a);
 void launch_resblock(const ResArgs& a, hipStream_t stream);
+bool resblock_up_supported(const ResArgs& a);
+void launch_resblock_up(const ResArgs& a, hipStream_t stream);
 
 
 // AR-step bookkeeping (runtime_native_safetensors.go:176-192 per slot, on device)

@@ -260,7 +260,7 @@ struct Walker {
     }
     // ConvTranspose1d [Cin, Cout, k=2s], first L*s outputs kept (mimi.go:116-125): out[t*s + r, oc] =
     //   sum_ic x[t-1, ic] * W[ic, oc, r + s] + x[t, ic] * W[ic, oc, r]   -> GEMM operand [(r, oc)][(j, ic)], j = 0: x[t-1], 1: x[t]
-    Lin convtr_as_gemm(const std::string& name, int stride, int* cin_out, int* cout_out) {
+    Lin convtr_as_gemm(const std::string& name, int stride, int* cin_out, int* cout_out, bool frag16 = false) {
         Lin l;
         const std::string wn = name + ".weight";
         expect_rank(wn, 3);
@@ -270,7 +270,7 @@ struct Walker {
         *cout_out = oc;
         l.out = stride * oc;
         l.in = 2 * ic;
-        l.w = add_mat((size_t)l.out * l.in, [&](float* dst) {
+        auto fill = [&](float* dst) {
             std::vector<float> w = load(wn);
             for (int r = 0; r < stride; r++)
                 for (int o = 0; o < oc; o++)
@@ -279,7 +279,9 @@ struct Walker {
                         dst[row * 2 * ic + c] = w[((size_t)c * oc + o) * k + r + stride];
                         dst[row * 2 * ic + ic + c] = w[((size_t)c * oc + o) * k + r];
                     }
-        }, &l.bf16);
+        };
+        l.w = add_mat((size_t)l.out * l.in, fill, &l.bf16);
+        if (frag16 && bf16w) add_frag16(l, fill);   // the last transposed convolution inside the fused block (resblock_up.hip)
         if (has(name + ".bias"))
             l.b = add_f32((size_t)l.out, [&](float* dst) {
                 std::vector<float> b = load(name + ".bias");
@@ -493,7 +495,7 @@ struct Walker {
         d.sea_ch[0] = d.init_conv.out;
         static const int up_idx[3] = {2, 5, 8}, rb_idx[3] = {3, 6, 9};
         for (int j = 0; j < 3; j++) {
-            d.up[j] = convtr_as_gemm(mi + "decoder.model." + std::to_string(up_idx[j]) + ".convtr", d.strides[j], &cin, &cout);
+            d.up[j] = convtr_as_gemm(mi + "decoder.model." + std::to_string(up_idx[j]) + ".convtr", d.strides[j], &cin, &cout, j == 2);
             if (cin != d.sea_ch[j]) throw Error(PTTS_EFORMAT, "native: decoder convtr input channels mismatch");
             d.sea_ch[j + 1] = cout;
             int c1 = 0, c2 = 0;

@@ -855,6 +855,27 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs gu = mk(m, in + (size_t)(Pin - 1 + r0) * cin, seg(cin, rn, in_bs), d.up[j],
                          u + (size_t)(Pout + (int64_t)r0 * st) * cout, seg((int64_t)st * cout, rn, u_bs), B * rn);
         // elu(x) precedes every transposed conv: c0 was activated in the initConv epilogue, uo[j-1] in its residual epilogue
+        if (j == 2 && d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 && d.rb2[j].bf16 && d.up[j].wf != NONE) {
+            // the last stage as ONE kernel: transposed convolution + residual block + final convolution (resblock_up.hip); u[2] is never written
+            static const int want = [] { const char* e = getenv("PTTS_FUSE_UP"); return e ? atoi(e) : 1; }();   // A/B measurement
+            ResArgs rr;
+            rr.u = u; rr.u_bs = u_bs; rr.pad = Pout; rr.uo = uo;
+            rr.w1 = m.at<uint8_t>(d.rb1[j].wf); rr.b1 = m.at<float>(d.rb1[j].b);
+            rr.w2 = m.at<uint8_t>(d.rb2[j].wf); rr.b2 = m.at<float>(d.rb2[j].b);
+            rr.B = B; rr.L = Lout; rr.t0 = r0 * st; rr.t1 = (r0 + rn) * st;
+            rr.C = cout; rr.H = hid; rr.k1 = d.rb_k1[j]; rr.k2 = d.rb_k2[j]; rr.w_bf16 = 1;
+            rr.final_conv = 1; rr.kf = d.final_k; rr.wf_hi = m.at<uint8_t>(d.final_wf); rr.wf_lo = m.at<uint8_t>(d.final_wf_lo); rr.bf = m.at<float>(d.final_b);
+            rr.pcm = pcm; rr.pcm_bs = w.Ls[3]; rr.pcm_rows = pcm_rows;
+            rr.fuse_up = 1; rr.xin = in; rr.x_bs = in_bs; rr.x_pad = Pin; rr.x_L = Lin_; rr.CI = cin; rr.up_stride = st;
+            rr.wup = m.at<uint8_t>(d.up[j].wf); rr.bup = m.at<float>(d.up[j].b);
+            if (want && resblock_up_supported(rr)) {
+                launch_resblock_up(rr, s);
+                if (rows_used && pcm_rows) *rows_used = true;
+                final_done = true;
+                r0 *= st; rn *= st;
+                continue;
+            }
+        }
         launch_gemm(gu, s);
         r0 *= st; rn *= st;
         // residual block: x + conv_k1(elu(conv_k3(elu(x))))  (mimi.go:146-164); x stays in u, elu(sum) goes to uo -- the

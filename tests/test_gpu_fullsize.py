@@ -269,3 +269,29 @@ def test_config2_full_length_125_frames_bf16(pkg, full):
     dv.close()
     gm.close()
     om.close()
+
+
+def test_last_stage_as_one_kernel_gives_the_two_launch_samples_bit_for_bit(pkg, full):
+    """k_resblock_up (transposed convolution 128 -> 64 stride 4 + residual block + final convolution in ONE kernel; mimi.go:740-788) is taken
+    when a decode has at least 8 tiles per CU -- two utterances of 100 frames do, one does not -- and keeps every product's k order: the
+    samples of an utterance must be the same BITS from the fused kernel (in a batch of two) and from k_gemm_wres + k_resblock (alone).
+    The head of the fused batch is also held against the oracle's decoder."""
+    cfg, paths, voice = full
+    gm = pkg.Model.open(paths["BF16"], device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=4)
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((2, 100, cfg.ldim)) * 0.5).astype(np.float32)
+    pkg.runtime.launch_counts(True)
+    both, _, _ = gm.decode_stages(x)
+    c2 = pkg.runtime.launch_counts(False)
+    assert c2.get("k_resblock_up+final", 0) == 1 and c2.get("k_resblock+final", 0) == 0, c2
+    for u in (0, 1):
+        pkg.runtime.launch_counts(True)
+        one, _, _ = gm.decode_stages(x[u:u + 1])
+        c1 = pkg.runtime.launch_counts(False)
+        assert c1.get("k_resblock+final", 0) == 1 and c1.get("k_resblock_up+final", 0) == 0, c1
+        assert np.array_equal(both[u], one[0]), (u, float(np.abs(both[u] - one[0]).max()))
+    om = O.OracleModel.from_file(paths["BF16"])
+    want = om.mimi_decode(om.latent_to_mimi(x[0][:6]))           # the decoder is causal: 6 frames of the oracle = the first 6 of 100
+    parity("fused last stage pcm (6 frames, bf16 weights)", both[0][: want.shape[-1]], want.reshape(-1), 2e-4, 5e-2)
+    om.close()
+    gm.close()
