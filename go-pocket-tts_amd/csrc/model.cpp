@@ -281,7 +281,20 @@ struct Walker {
                     }
         };
         l.w = add_mat((size_t)l.out * l.in, fill, &l.bf16);
-        if (frag16 && bf16w) add_frag16(l, fill);   // the last transposed convolution inside the fused block (resblock_up.hip)
+        if (frag16 && bf16w && stride == 4 && oc == 64) {
+            // the last transposed convolution inside the fused block (resblock_up.hip): fragment-ordered, with the output columns regrouped so
+            // that column q of the 16-column tile T holds phase q >> 2 of channel 8 (T >> 1) + 4 (T & 1) + (q & 3) -- a lane of the product then
+            // owns four channels of ONE phase and the 64 lanes of a wave 64 consecutive output rows (conflict-free LDS writes)
+            add_frag16(l, [&](float* dst) {
+                std::vector<float> rm((size_t)l.out * l.in);
+                fill(rm.data());
+                for (int T = 0; T < l.out / 16; T++)
+                    for (int q = 0; q < 16; q++) {
+                        const int n = (q >> 2) * oc + 8 * (T >> 1) + 4 * (T & 1) + (q & 3);
+                        std::copy(rm.begin() + (size_t)n * l.in, rm.begin() + (size_t)(n + 1) * l.in, dst + (size_t)(T * 16 + q) * l.in);
+                    }
+            });
+        }
         if (has(name + ".bias"))
             l.b = add_f32((size_t)l.out, [&](float* dst) {
                 std::vector<float> b = load(name + ".bias");

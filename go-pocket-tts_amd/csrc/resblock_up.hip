@@ -11,7 +11,8 @@
 //   X  x rows (33 x 128 f32, requested one tile ahead) -> bf16 hi / lo planes in LDS (XOR-swizzled 16-byte chunks)
 //   0  u = transposed convolution as a product [32 rows x 256 k] x [256 k x 256 n], k = (x[t-1] | x[t]), n = (phase, channel).  The
 //      256 x 256 bf16 weights do not fit LDS beside the rest: every wave keeps ITS 32 columns of them in registers for the whole kernel
-//      (64 VGPRs: two 16-column tiles x 8 k steps, fragment-ordered) and multiplies them with all 32 rows.  u (+ bias) goes to LDS twice:
+//      (64 VGPRs: two 16-column tiles x 8 k steps, fragment-ordered; a tile = all four phases of four channels, so that a wave's lanes end
+//      up with 64 consecutive output rows: conflict-free LDS writes) and multiplies them with all 32 rows.  u (+ bias) goes to LDS twice:
 //      as f32 (the residual operand of stage C) and, behind ELU, as the hi / lo planes stage B reads -- what k_resblock's stage A writes
 //   B, C, D  as in k_resblock (resblock.hip): conv_k3 + ELU -> hidden planes, conv_k1 + residual + ELU -> planes, final conv -> PCM
 // Numerics: every product as in k_gemm_wres / k_resblock (activations hi + lo, bf16 weights, f32 accumulation, the same k order within
@@ -49,6 +50,10 @@ union FragU {
 // f32 u tile [128 rows][64 channels]: 16-byte chunk k of row i sits at chunk k ^ usw(i).  Stage 0 writes rows 4 r + phase (r = lane & 15),
 // stage C reads rows 16 wave + r: with this XOR both hit 16 different chunks per lane group.
 __device__ __forceinline__ int usw(int i) { return (i ^ (i >> 2)) & 15; }
+// the elu(u) / sum planes: k_resblock swizzles chunk k of plane row rho to k ^ rho, which suits lanes that hold CONSECUTIVE rows (its stages, and
+// stages B .. D here).  Stage 0's lanes hold rows four apart (one phase of 16 consecutive input rows): with rho ^ (rho >> 2) instead, eight such
+// rows hit eight different chunks as well (k ^ rho alone: two -- an 8-way bank conflict on every plane write of the stage).
+__device__ __forceinline__ int esw(int rho) { return rho ^ (rho >> 2); }
 
 }  // namespace
 
@@ -56,8 +61,12 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
     constexpr int C = 64, H = 32, CI = 128, NW = 8, NTH = NW * 64;
     constexpr int TR = NW * 16, HALO = 4, TOUT = TR - HALO;          // 128 output rows per tile, 124 of them new
     constexpr int TI = TR / 4, XR = TI + 1;                          // 32 input rows + the one before them
-    constexpr int ROWB = C * 2, HROWB = H * 2, XROWB = CI * 2;       // bytes per plane row
-    constexpr int CM = C / 8 - 1, HM = H / 8 - 1, XM = CI / 8 - 1;   // chunk-swizzle masks
+    constexpr int ROWB = C * 2;                                      // bytes per row of the elu(u) / sum planes (XOR-swizzled chunks: esw)
+    // the input planes and the hidden planes are PADDED instead (a row pitch of 32 resp. 16 bytes more than the row, chunks in place): by the
+    // lane groups a ds_read_b128 is served in, 16 consecutive rows then cover all banks whatever the first row (the XOR form was 2-way on
+    // every read that starts at an odd row: the x[t] half of the window) -- tools/probes/lds_conflicts.py is the model these came from
+    constexpr int HROWB = H * 2 + 16, XROWB = CI * 2 + 32;
+    constexpr int CM = C / 8 - 1;                                    // chunk-swizzle mask
     constexpr int PLANE = (TR + 2) * ROWB, HPLANE = TR * HROWB, XPLANE = XR * XROWB;
     constexpr int F1 = (H / 16) * (3 * C / 32), F2 = (C / 16) * (H / 32), FF = 2 * (3 * C / 32);   // weight fragments (1 KiB each)
     constexpr int UT_BYTES = TR * C * 4;
@@ -135,7 +144,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                 unsigned h01, l01, h23, l23;
                 split2u(v.x, v.y, h01, l01);
                 split2u(v.z, v.w, h23, l23);
-                const int off = r * XROWB + ((((c >> 3) ^ r) & XM) << 4) + ((c & 4) << 1);
+                const int off = r * XROWB + c * 2;
                 *reinterpret_cast<uint2*>(x_hi + off) = make_uint2(h01, h23);
                 *reinterpret_cast<uint2*>(x_lo + off) = make_uint2(l01, l23);
             }
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
 #pragma unroll
                 for (int rt = 0; rt < 2; rt++) {
                     const int rho = rt * 16 + r16 + jr;
-                    const int off = rho * XROWB + ((((c0 >> 3) + g) ^ rho) & XM) * 16;
+                    const int off = rho * XROWB + ((c0 >> 3) + g) * 16;
                     FragU xh, xl;
                     xh.q = *reinterpret_cast<const uint4*>(x_hi + off);
                     xl.q = *reinterpret_cast<const uint4*>(x_lo + off);
@@ -171,17 +180,18 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                     }
                 }
             }
-            // lane: input row rt*16 + r16, columns (2 wave + ct) 16 + 4 g .. + 3 = phase wave >> 1, channels (wave & 1) 32 + ct 16 + 4 g .. + 3
-            const int ph = wave >> 1;
+            // lane: input row rt*16 + r16; the weight columns are grouped (model.cpp) so that columns 4 g .. 4 g + 3 of tile (wave, ct) are phase g of
+            // channels 8 wave + 4 ct .. + 3: the lane's four values are four channels of output row 4 (input row) + g, and a wave's 64 lanes
+            // hold 64 consecutive output rows
 #pragma unroll
             for (int rt = 0; rt < 2; rt++) {
-                const int i = 4 * (rt * 16 + r16) + ph;        // tile row of the output
+                const int i = 4 * (rt * 16 + r16) + g;         // tile row of the output
                 const int gr = row0 + i;
                 const bool ok = gr >= 0 && gr < a.L;
                 const int rho = i + 2;
 #pragma unroll
                 for (int ct = 0; ct < 2; ct++) {
-                    const int ch = (wave & 1) * 32 + ct * 16 + 4 * g;
+                    const int ch = 8 * wave + 4 * ct;
                     const float4 b = *reinterpret_cast<const float4*>(blu + ch);
                     float4 v = make_float4(acc[ct][rt][0] + b.x, acc[ct][rt][1] + b.y, acc[ct][rt][2] + b.z, acc[ct][rt][3] + b.w);
                     if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);   // rows before the utterance (zero history) or past its end
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                     unsigned h01, l01, h23, l23;
                     split2u(elu_fast(v.x), elu_fast(v.y), h01, l01);
                     split2u(elu_fast(v.z), elu_fast(v.w), h23, l23);
-                    const int off = rho * ROWB + ((((ch >> 3) ^ rho) & CM) << 4) + ((ch & 4) << 1);
+                    const int off = rho * ROWB + ((((ch >> 3) ^ esw(rho)) & CM) << 4) + ((ch & 4) << 1);
                     *reinterpret_cast<uint2*>(eu_hi + off) = make_uint2(h01, h23);
                     *reinterpret_cast<uint2*>(eu_lo + off) = make_uint2(l01, l23);
                 }
@@ -211,7 +221,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
             for (int s = 0; s < KS; s++) {
                 const int tap = (s * 32) / C, c0 = (s * 32) % C;
                 const int rho = i_lane + tap;             // window row i-2+tap, stored at rho = that + 2
-                const int off = rho * ROWB + ((((c0 >> 3) + g) ^ rho) & CM) * 16;
+                const int off = rho * ROWB + ((((c0 >> 3) + g) ^ esw(rho)) & CM) * 16;
                 FragU xh, xl;
                 xh.q = *reinterpret_cast<const uint4*>(eu_hi + off);
                 xl.q = *reinterpret_cast<const uint4*>(eu_lo + off);
@@ -230,7 +240,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                 unsigned h01, l01, h23, l23;
                 split2u(elu_fast(acc[n][0] + b.x), elu_fast(acc[n][1] + b.y), h01, l01);
                 split2u(elu_fast(acc[n][2] + b.z), elu_fast(acc[n][3] + b.w), h23, l23);
-                const int off = i_lane * HROWB + ((((ch >> 3) ^ i_lane) & HM) << 4) + ((ch & 4) << 1);
+                const int off = i_lane * HROWB + ch * 2;
                 *reinterpret_cast<uint2*>(h_hi + off) = make_uint2(h01, h23);
                 *reinterpret_cast<uint2*>(h_lo + off) = make_uint2(l01, l23);
             }
@@ -246,7 +256,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
             const uint4* w2 = wl2 + lane;
 #pragma unroll
             for (int s = 0; s < KS; s++) {
-                const int off = i_lane * HROWB + (((s * 4 + g) ^ i_lane) & HM) * 16;
+                const int off = i_lane * HROWB + (s * 4 + g) * 16;
                 FragU xh, xl;
                 xh.q = *reinterpret_cast<const uint4*>(h_hi + off);
                 xl.q = *reinterpret_cast<const uint4*>(h_lo + off);
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                 unsigned h01, l01, h23, l23;
                 split2u(v.x, v.y, h01, l01);
                 split2u(v.z, v.w, h23, l23);
-                const int off = rho * ROWB + ((((ch >> 3) ^ rho) & CM) << 4) + ((ch & 4) << 1);
+                const int off = rho * ROWB + ((((ch >> 3) ^ esw(rho)) & CM) << 4) + ((ch & 4) << 1);
                 *reinterpret_cast<uint2*>(eu_hi + off) = make_uint2(h01, h23);
                 *reinterpret_cast<uint2*>(eu_lo + off) = make_uint2(l01, l23);
             }
@@ -287,7 +297,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
             for (int s = 0; s < KS; s++) {
                 const int tap = (s * 32) / C, c0 = (s * 32) % C;
                 const int rho = i_lane + tap;
-                const int off = rho * ROWB + ((((c0 >> 3) + g) ^ rho) & CM) * 16;
+                const int off = rho * ROWB + ((((c0 >> 3) + g) ^ esw(rho)) & CM) * 16;
                 FragU xh, xl, wh, wl;
                 xh.q = *reinterpret_cast<const uint4*>(eu_hi + off);
                 xl.q = *reinterpret_cast<const uint4*>(eu_lo + off);
