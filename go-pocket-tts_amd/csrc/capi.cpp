@@ -840,7 +840,10 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         // out_proj / linear2), 0x400: activations behind a prologue ELU, 0x800: a per-column scale
         const int epi = epi_flags & 0xff;
         const bool rope = epi_flags & 0x100, inplace = epi_flags & 0x200;
-        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc = (size_t)M * N;
+        const size_t na = (size_t)M * K, nw = (size_t)N * K, nc1 = (size_t)M * N;
+        const int S = (epi_flags & 0x4000) ? K / 1024 : 1;   // 0x4000: split-K in 1024-deep slices (raw sums, plane z at C + z M N)
+        if (S < 1 || (S > 1 && K % 1024)) throw Error(PTTS_EINVAL, "split-K probe needs K % 1024 == 0");
+        const size_t nc = nc1 * (size_t)S;       // values compared: every plane
         std::vector<float> ha(na), hw(nw), hb((size_t)N);
         uint32_t st = 12345u;
         auto rnd = [&] { st = st * 1664525u + 1013904223u; return ((float)(st >> 8) / 8388608.0f) - 1.0f; };
@@ -871,6 +874,7 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
         g.R = dR.as<float>(); g.epi = epi;
         g.M = M; g.N = N; g.K = K;
         if (epi_flags & 0x400) g.aop = AOP_ELU;
+        if (S > 1) { g.kslice = 1024; g.zstride = (int64_t)nc1; g.bias = nullptr; }
         if (epi_flags & 0x800) g.scale = dB.as<float>();   // a per-column scale (the decoder's layer scale): the bias values serve
         if (rope) {
             g.rope_cos = dCos.as<float>(); g.rope_sin = dSin.as<float>(); g.rope_cols = N / 3 * 2; g.rope_hd = 64; g.rope_pos0 = 0; g.rope_rows_per_seg = 2000;
@@ -912,7 +916,7 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
             for (size_t i = 0; i < nc; i++) {
                 float d = std::fabs(c1[i] - c2[i]);
                 if (!(d <= md)) md = d;
-                if (d != 0 && nbad++ < 12) fprintf(stderr, "ptts_debug_gemm: variant %d vs reference at row %zu column %zu: %.9g vs %.9g\n", variant, i / N, i % N, c1[i], c2[i]);
+                if (d != 0 && nbad++ < 12) fprintf(stderr, "ptts_debug_gemm: variant %d vs reference at plane %zu row %zu column %zu: %.9g vs %.9g\n", variant, i / nc1, (i % nc1) / N, i % N, c1[i], c2[i]);
             }
             if (nbad) fprintf(stderr, "ptts_debug_gemm: %zu of %zu values differ from the reference kernel's\n", nbad, nc);
             for (int rep = 0; rep < 3; rep++) {

@@ -72,13 +72,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     if (pan >= npan) return;
     const int m0 = pan * BM + wave * 32, n0 = (jb % ncol) * BN;
 
+    // split-K (a.kslice > 0, the prompt prefill's linear2): blockIdx.y owns k in [kz, kz + KL) and writes its raw sums to plane blockIdx.y of C
+    const int kz = blockIdx.y * a.kslice;
+    const int KL = a.kslice ? min(a.kslice, a.K - kz) : a.K;
     const float* aptr[2];
 #pragma unroll
-    for (int t = 0; t < 2; t++) aptr[t] = a.A + row_off(a.amap, min(m0 + t * 16 + r16, a.M - 1)) + g * 8;
+    for (int t = 0; t < 2; t++) aptr[t] = a.A + row_off(a.amap, min(m0 + t * 16 + r16, a.M - 1)) + kz + g * 8;
     // weights: thread -> (column tid / 8 + 64 NW/8 p, k piece tid % 8); N % BN == 0 (host), so no column needs a bound
     constexpr int CPP = NTH / PPR;                                       // columns between two pieces of a thread
     const int wn = tid / PPR, wk = tid % PPR;                            // 8 k at wk*8: sub-chunk wk>>2, chunk wk&3
-    const char* wsrc = (const char*)a.W + ((int64_t)(n0 + wn) * a.ldw + wk * 8) * 2;
+    const char* wsrc = (const char*)a.W + ((int64_t)(n0 + wn) * a.ldw + kz + wk * 8) * 2;
     const int64_t wstep = (int64_t)CPP * a.ldw * 2;
     const int wdst = (wk >> 2) * HALF + wn * 64 + (((wk & 3) ^ fw5(wn)) << 4);   // CPP % 16 == 0: the swizzle of column wn + CPP p is wn's
     static_assert(CPP % 16 == 0, "");
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int n = 0; n < NT; n++) acc[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nchunks = a.K / CH, nsteps = nchunks * SPC;      // K % CH == 0 (host)
+    const int nchunks = KL / CH, nsteps = nchunks * SPC;       // K (and a K slice) % CH == 0 (host)
     float4 av[SPC][2][2];
     auto a_load = [&](int i, float4 (&dst)[2][2]) {
 #pragma unroll
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
         for (int t = 0; t < 2; t++) {
             const int m = m0 + t * 16 + r16, mc = min(m, a.M - 1);
-            const int64_t ro = row_off(a.cmap, mc);
+            const int64_t ro = row_off(a.cmap, mc) + blockIdx.y * a.zstride;
             int64_t tab = 0;
             if constexpr (ROPE) {
                 const int pos = a.rope_row_pos ? a.rope_row_pos[mc] : a.rope_pos0 + (a.rope_rows_per_seg ? mc % a.rope_rows_per_seg : mc);
@@ -266,7 +269,8 @@ bool gemm5_supported(const GemmArgs& a) {
     const bool res = a.epi >= EPI_RESADD;
     const bool epi_ok = a.epi == EPI_NONE || a.epi == EPI_GELU || a.epi == EPI_ELU || a.epi == EPI_RESADD || a.epi == EPI_SCALE_RESADD || a.epi == EPI_RESADD_ELU;
     static const int min_m = [] { const char* e = getenv("PTTS_GEMM5_MIN_M"); return e ? atoi(e) : 1024; }();   // A/B measurement (16384: the decoder at many rows only)
-    return a.w_bf16 && epi_ok && a.M >= min_m && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && !a.kslice && !a.tail &&
+    return a.w_bf16 && epi_ok && a.M >= min_m && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && !a.tail &&
+           (!a.kslice || (a.kslice % 64 == 0 && a.K % a.kslice == 0 && a.epi == EPI_NONE && !a.bias && !a.rope_cos && a.zstride % 4 == 0)) &&
            aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0 && a.ldw % 8 == 0 && aligned16(a.W) && (int64_t)a.N * a.ldw * 2 >= (int64_t)a.N * 4 &&
            aligned16(a.C) && a.cmap.ld % 4 == 0 && a.cmap.batch_stride % 4 == 0 && (!a.bias || aligned16(a.bias)) && (!a.scale || aligned16(a.scale)) &&
            (!res || aligned16(a.R)) && (!a.rope_cos || (a.rope_hd == 64 && a.rope_cols % 64 == 0 && a.epi == EPI_NONE));
@@ -275,13 +279,13 @@ bool gemm5_supported(const GemmArgs& a) {
 template <int BN, int NW, int ABL = 0>
 static void launch5_cfg(const GemmArgs& a, hipStream_t stream) {
     const int ncol = (a.N + BN - 1) / BN, npan = (a.M + NW * 32 - 1) / (NW * 32);
-    dim3 grid((unsigned)(((npan + 7) / 8) * 8 * ncol));
+    dim3 grid((unsigned)(((npan + 7) / 8) * 8 * ncol), (unsigned)(a.kslice ? a.K / a.kslice : 1));
     if (a.aop == AOP_ELU) hipLaunchKernelGGL((k_gemm5<BN, NW, true, ABL>), grid, dim3(NW * 64), 0, stream, a);
     else hipLaunchKernelGGL((k_gemm5<BN, NW, false, ABL>), grid, dim3(NW * 64), 0, stream, a);
 }
 
 void launch_gemm5(const GemmArgs& a, hipStream_t stream) {
-    note_launch(a.rope_cos ? "k_gemm5+rope" : "k_gemm5");
+    note_launch(a.rope_cos ? "k_gemm5+rope" : a.kslice ? "k_gemm5+splitk" : "k_gemm5");
     const int cfg = g_gemm5_cfg;
     const bool wide = a.N % 256 == 0;   // (N = 640: 128-column tiles)
     switch (cfg) {

@@ -451,8 +451,9 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
             if (R < 16384 && Sg > 1 && Sg <= 8) {
                 DevBuf& pb = m.work(9, (size_t)Sg * R * D * f);
                 gs.C = pb.as<float>(); gs.cmap = flat(D);
-                if (gemm3_supported(gs)) {
-                    launch_gemm3(gs, s);
+                if (gemm5_supported(gs) || gemm3_supported(gs)) {
+                    if (gemm5_supported(gs)) launch_gemm5(gs, s);   // (bf16 weights from 1024 rows; the same k order within a slice: the same planes)
+                    else launch_gemm3(gs, s);
                     pend_partial = pb.as<float>(); pend_split = Sg; pend_bias = m.at<float>(L.l2.b);
                     continue;
                 }

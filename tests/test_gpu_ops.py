@@ -204,14 +204,15 @@ def test_weights_resident_gemm_equals_the_tile_gemm(pkg, shape):
 
 @pytest.mark.parametrize("shape", [(16384, 1536, 512, 0x100), (16640, 1536, 512, 0x000), (16384, 512, 512, 0x204), (16384, 512, 2048, 0x204), (16384, 512, 3584, 0x003),
                                    (16384, 1536, 1024, 0x000), (49152, 128, 768, 0x403), (49152, 256, 128, 0x008), (16384, 2048, 512, 0x001), (16400, 256, 64, 0x000),
-                                   (1600, 3072, 1024, 0x100), (1600, 1024, 1024, 0x204), (1600, 4096, 1024, 0x001), (1030, 128, 192, 0x003)])
+                                   (1600, 3072, 1024, 0x100), (1600, 1024, 1024, 0x204), (1600, 4096, 1024, 0x001), (1030, 128, 192, 0x003),
+                                   (1600, 1024, 4096, 0x4000), (16384, 512, 2048, 0x4000)])
 def test_many_row_gemm5_equals_gemm3_bit_for_bit_and_itself_run_to_run(pkg, shape):
     """k_gemm5 (bf16 weights; 256-row tiles from 16384 rows: the decoder's deep GEMMs at the benchmark's batch; 128 x 128 tiles from 1024 rows:
     the prompt prefill's projections, the last four shapes) keeps k_gemm3's k order, so every form the
     decoder uses must give k_gemm3's bits: the qkv projection with the RoPE epilogue (positions restarting every 2000 rows), plain bias,
     a residual read from the output buffer itself (out_proj / linear2 update the stream in place), ELU (first convolution), a prologue
     ELU (the residual block's first convolution: 128 columns), residual + ELU, GELU, a row count that is no multiple of the tile and a
-    single weight chunk (K = 64).  The debug entry also runs the variant three more times and compares bits (a race would show)."""
+    single weight chunk (K = 64), split-K in 1024-deep slices (the prefill's linear2: raw sums per plane).  The debug entry also runs the variant three more times and compares bits (a race would show)."""
     import ctypes as C
     M, N, K, epi = shape
     L = pkg.runtime.lib()

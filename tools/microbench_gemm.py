@@ -14,7 +14,7 @@ variants = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [2
 only = sys.argv[3].split(",") if len(sys.argv) > 3 else None
 R = 128000
 # epilogue codes: +0x100 RoPE, +0x200 residual read from the output buffer, +0x400 prologue ELU (capi.cpp ptts_debug_gemm)
-shapes = [("pf_qkv", 1600, 3072, 1024, 0x100), ("pf_out", 1600, 1024, 1024, 4), ("pf_l1", 1600, 4096, 1024, 1), ("pf_l2", 1600, 1024, 4096, 4),
+shapes = [("pf_qkv", 1600, 3072, 1024, 0x100), ("pf_out", 1600, 1024, 1024, 4), ("pf_l1", 1600, 4096, 1024, 1), ("pf_l2", 1600, 1024, 4096, 4), ("pf_l2_sk", 1600, 1024, 4096, 0x4000),
           ("qkv", R, 1536, 512, 0), ("qkv_rope", R, 1536, 512, 0x100), ("out_proj_ip", R, 512, 512, 0x205), ("out_proj_ls", R, 512, 512, 0xa05), ("ffn2_ip", R, 512, 2048, 0x205), ("rb1_0_elu", 6 * R, 128, 768, 0x403), ("rb2_0_re", 6 * R, 256, 128, 8), ("out_proj", R, 512, 512, 4), ("ffn1", R, 2048, 512, 1), ("ffn2", R, 512, 2048, 4),
           ("init_conv", R, 512, 3584, 3), ("up1", R, 1536, 1024, 0), ("rb1_0", 6 * R, 128, 768, 3), ("rb2_0", 6 * R, 256, 128, 4),
           ("up2", 6 * R, 640, 512, 0), ("rb1_1", 30 * R, 64, 384, 3), ("rb2_1", 30 * R, 128, 64, 4), ("up3", 30 * R, 256, 256, 0),
