@@ -295,3 +295,38 @@ def test_last_stage_as_one_kernel_gives_the_two_launch_samples_bit_for_bit(pkg, 
     parity("fused last stage pcm (6 frames, bf16 weights)", both[0][: want.shape[-1]], want.reshape(-1), 2e-4, 5e-2)
     om.close()
     gm.close()
+
+
+def test_last_stage_kernel_decodes_frame_ranges_behind_the_ar_loop(pkg, full):
+    """k_resblock_up in RANGE mode (rows t0 .. t1 of every utterance with t0 > 0; its halo rows are recomputed from the previous stage's
+    rows, which persist in the workspace): 16 utterances of 48 frames streamed in 16-frame ranges (3968 tiles per range: the fused
+    kernel is taken for each) against the same call decoded at once.  Latents are the same bits (streaming only changes WHEN frames are
+    decoded); every sample is delivered once and in order; the audio equals the non-streamed audio to the +/-2 LSB a differently tiled
+    decode is allowed (the window attention's key tiles start elsewhere)."""
+    cfg, paths, voice = full
+    gm = pkg.Model.open(paths["BF16"], device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=16)
+    dv = gm.upload_voice(pkg.VoiceModelState(voice))
+    toks = [p for p in pkg.synth.make_prompts(16, 20, 4000, seed=9)]
+    frames, per = 48, 16
+    base = dict(eos_threshold=float("inf"), max_steps=frames, device_voice=dv, want_latents=True, pcm16=True)
+    whole = gm.generate_batch(toks, [pkg.RuntimeGenerateConfig(**base)] * 16)
+    chunks = [[] for _ in toks]
+
+    def mk(i):
+        def cb(off, x):
+            chunks[i].append((off, x.copy()))
+        return cb
+
+    pkg.runtime.launch_counts(True)
+    got = gm.generate_batch(toks, [pkg.RuntimeGenerateConfig(pcm_callback=mk(i), stream_frames=per, **base) for i in range(16)])
+    counts = pkg.runtime.launch_counts(False)
+    assert counts.get("k_resblock_up+final", 0) >= 2 and counts.get("k_resblock+final", 0) == 0, counts   # (one launch per decoded range)
+    for i in range(16):
+        assert got[i].n_frames == frames and np.array_equal(got[i].latents, whole[i].latents)
+        offs = [o for o, _ in chunks[i]]
+        sizes = [c.size for _, c in chunks[i]]
+        assert offs[0] == 0 and all(offs[k + 1] == offs[k] + sizes[k] for k in range(len(offs) - 1)) and offs[-1] + sizes[-1] == frames * 1920
+        assert np.array_equal(np.concatenate([c for _, c in chunks[i]]), got[i].pcm)
+        assert np.abs(got[i].pcm.astype(np.int32) - whole[i].pcm.astype(np.int32)).max() <= 2, i
+    dv.close()
+    gm.close()
