@@ -86,9 +86,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int wdst = (wk >> 2) * HALF + wn * 64 + (((wk & 3) ^ fw5(wn)) << 4);   // CPP % 16 == 0: the swizzle of column wn + CPP p is wn's
     static_assert(CPP % 16 == 0, "");
     u32x4 wreg[PPT];
+    // k offset of the c-th 64-deep chunk.  A causal convolution as a product reads, for output row r, the window rows r-taps+1 .. r (K = taps x C,
+    // tap-major in memory and in the weights).  Walked in that order a wave meets an input row again C / 64 chunks later -- once per tap -- and by
+    // then the line has left L1 and mostly L2: the first convolution (7 taps) fetched its input 6x from HBM (FETCH_SIZE, profiles/r3_pmc_mimi.txt).
+    // With GemmArgs::win_taps the chunks are walked channel-block-major instead -- (block 0: tap 0, 1, .. ), (block 1: ..) -- so the taps' reads of one
+    // line follow each other.  Sums are per k chunk either way: the order of the chunks changes the last bits, not the products.
+    const int wtaps = a.win_taps;
+    auto koff = [&](int c) { return wtaps ? (c % wtaps) * a.win_c + (c / wtaps) * CH : c * CH; };
     auto w_load = [&](int c) {
+        const int64_t ko = (int64_t)koff(c) * 2;
 #pragma unroll
-        for (int p = 0; p < PPT; p++) wreg[p] = *reinterpret_cast<const u32x4*>(wsrc + p * wstep + (int64_t)c * (CH * 2));
+        for (int p = 0; p < PPT; p++) wreg[p] = *reinterpret_cast<const u32x4*>(wsrc + p * wstep + ko);
     };
     auto w_store = [&](int stage) {
 #pragma unroll
@@ -104,10 +112,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     const int nchunks = KL / CH, nsteps = nchunks * SPC;       // K (and a K slice) % CH == 0 (host)
     float4 av[SPC][2][2];
     auto a_load = [&](int i, float4 (&dst)[2][2]) {
+        const int ko = koff(i / SPC) + (i % SPC) * 32;
 #pragma unroll
         for (int t = 0; t < 2; t++) {
-            dst[t][0] = *reinterpret_cast<const float4*>(aptr[t] + i * 32);
-            dst[t][1] = *reinterpret_cast<const float4*>(aptr[t] + i * 32 + 4);
+            dst[t][0] = *reinterpret_cast<const float4*>(aptr[t] + ko);
+            dst[t][1] = *reinterpret_cast<const float4*>(aptr[t] + ko + 4);
         }
     };
     w_load(0);
@@ -266,6 +275,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 }
 
 bool gemm5_supported(const GemmArgs& a) {
+    if (a.win_taps && (a.win_taps < 2 || a.win_c % 64 || a.K != a.win_taps * a.win_c || a.kslice)) return false;
     const bool res = a.epi >= EPI_RESADD;
     const bool epi_ok = a.epi == EPI_NONE || a.epi == EPI_GELU || a.epi == EPI_ELU || a.epi == EPI_RESADD || a.epi == EPI_SCALE_RESADD || a.epi == EPI_RESADD_ELU;
     static const int min_m = [] { const char* e = getenv("PTTS_GEMM5_MIN_M"); return e ? atoi(e) : 1024; }();   // A/B measurement (16384: the decoder at many rows only)

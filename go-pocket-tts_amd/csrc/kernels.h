@@ -53,6 +53,9 @@ struct GemmArgs {
     // k_gemm3 only: split-K.  kslice > 0: ceil(K / kslice) blocks share an output tile, block z multiplies k in
     // [z kslice, (z+1) kslice) and stores its raw sums at C + z * zstride (no bias, no epilogue: the consumer adds the planes)
     int kslice = 0; int64_t zstride = 0;
+    // k_gemm5 only: A's rows are the overlapping windows of a causal convolution (K = win_taps x win_c, row stride win_c): walk k channel-block-major
+    // (speed only: the taps' reads of one input line then follow each other; gemm5.hip)
+    int win_taps = 0, win_c = 0;
     float* tail = nullptr;           // k_skinny only: the LAST column goes, as acc + bias without the epilogue, to tail[m] instead of C
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;

@@ -841,6 +841,8 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs g = mk(m, w.up + (size_t)r0 * C, seg(C, rn, up_bs), d.init_conv, w.c0 + (size_t)(w.Ps[0] + r0) * ch,
                         seg(ch, rn, (int64_t)(w.Ps[0] + w.Ls[0]) * ch), B * rn);
         g.epi = EPI_ELU;  // x = elu(initConv(x))
+        static const int kperm = [] { const char* e = getenv("PTTS_CONV_KPERM"); return e ? atoi(e) : 1; }();   // A/B measurement
+        if (kperm && C % 64 == 0 && d.init_conv.in == d.init_k * C) { g.win_taps = d.init_k; g.win_c = C; }
         launch_gemm(g, s);
     }
     bool final_done = false;
@@ -912,6 +914,10 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs g1 = mk(m, u + (size_t)(Pout - (d.rb_k1[j] - 1) + r0) * cout, seg(cout, rn, u_bs), d.rb1[j],
                          hb + (size_t)(Ph + r0) * hid, seg(hid, rn, h_bs), B * rn);
         g1.aop = AOP_ELU; g1.epi = EPI_ELU;
+        {
+            static const int kperm = [] { const char* e = getenv("PTTS_CONV_KPERM"); return e ? atoi(e) : 1; }();   // A/B measurement
+            if (kperm && cout % 64 == 0 && d.rb1[j].in == d.rb_k1[j] * cout) { g1.win_taps = d.rb_k1[j]; g1.win_c = cout; }
+        }
         launch_gemm(g1, s);
         GemmArgs g2 = mk(m, hb + (size_t)r0 * hid, seg(hid, rn, h_bs), d.rb2[j], uo + (size_t)(Pout + r0) * cout, seg(cout, rn, u_bs), B * rn);
         g2.R = u + (size_t)(Pout + r0) * cout; g2.epi = EPI_RESADD_ELU;
