@@ -1327,10 +1327,12 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     };
     // graph replay without per-step host work (no step callbacks, no cancel flags, no ranges to decode on the way): several
     // steps per graph.  Slots that finish inside a graph are skipped by every kernel of the remaining steps (active flags).
-    static const int env_gsteps = [] { const char* e = getenv("PTTS_GRAPH_STEPS"); return e ? std::max(1, atoi(e)) : 5; }();   // measured: 1 -> 5: -0.2..-0.6 ms per 125-step batch, 25: -0.1 more
+    // 5 steps per graph; 25 when no request of the batch can end by EOS (threshold = +inf: every budget is known, so no replayed step can turn out to
+    // have been for nothing) -- measured on the 125-step batch: 1 -> 5 steps: -0.2..-0.6 ms, 5 -> 25: -0.5 ms, 125: -0.15 (one big graph is slower again)
+    static const int env_gsteps = [] { const char* e = getenv("PTTS_GRAPH_STEPS"); return e ? std::max(1, atoi(e)) : 0; }();
     bool any_cancel_flag = false;
     for (int i = 0; i < B; i++) any_cancel_flag |= reqs[idx[i]].cancel != nullptr;
-    const int gsteps = (use_graph && !any_cb && !any_cancel_flag && chunk > ms_max) ? env_gsteps : 1;
+    const int gsteps = (use_graph && !any_cb && !any_cancel_flag && chunk > ms_max) ? (env_gsteps ? env_gsteps : (may_stop ? 5 : 25)) : 1;
     const int ms_loop = std::min(ms_max, t_limit + 1);
     for (int step = 0; step < ms_loop;) {
         int n_cancel = 0;
@@ -1340,7 +1342,7 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
             n_cancel += cancelled[i];
         }
         if (n_cancel == B) break;
-        const int n_now = (gsteps > 1 && step + gsteps <= ms_loop) ? gsteps : 1;
+        const int n_now = (gsteps > 1 && step + gsteps <= ms_loop) ? gsteps : (gsteps > 5 && step + 5 <= ms_loop) ? 5 : 1;   // the tail: smaller graphs
         enqueue_step(b, lsd, use_graph, n_now);
         step += n_now;
         steps_run = step;
