@@ -254,6 +254,7 @@ def roofline_pass(pkg, model, wl, prompts, voice, traffic=None):
     durations; the same with the activation rows in and the outputs counted is reported beside it."""
     cfgs = gen_cfgs(pkg, wl, len(prompts), voice)
     toks = [np.ascontiguousarray(p, np.int64) for p in prompts]
+    model.generate_batch(toks, cfgs)   # untimed: whatever ran last on this model (another temperature, plain launches) may have dropped its step graphs -- re-capturing them belongs to no phase
     model.profile_enable(2)   # phases only: the call runs as configured (graph replay), HIP events at the phase boundaries
     try:
         model.generate_batch(toks, cfgs)

@@ -1023,13 +1023,20 @@ int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go
 // the batch).  Several steps per graph: the gap between two replays (~8 us of idle GPU) is paid once per graph.
 static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
     Model& m = *b.m;
-    if (b.graph_lsd != lsd || b.graph_noise != b.has_noise || (nsteps > 1 && b.graph_steps != nsteps)) {
+    if (b.graph_lsd != lsd || b.graph_noise != b.has_noise) {
         for (auto& row : b.graphs) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
         b.graph_lsd = lsd;
         b.graph_noise = b.has_noise;
-        if (nsteps > 1) b.graph_steps = nsteps;
+        b.graph_steps[0] = b.graph_steps[1] = 0;
     }
-    hipGraphExec_t& slot = b.graphs[ni][nsteps > 1 ? 1 : 0];
+    // three columns: single steps, the short graphs (5 steps: batches that may end by EOS, and the tail of the others), the long ones (25).  A
+    // column is re-captured only when ITS step count changes (a call that alternates 25 / 5 / 1 keeps all three)
+    const int col = nsteps <= 1 ? 0 : nsteps <= 5 ? 1 : 2;
+    if (col > 0 && b.graph_steps[col - 1] != nsteps) {
+        for (auto& row : b.graphs) if (row[col]) { (void)hipGraphExecDestroy(row[col]); row[col] = nullptr; }
+        b.graph_steps[col - 1] = nsteps;
+    }
+    hipGraphExec_t& slot = b.graphs[ni][col];
     if (slot) return slot;
     hipGraph_t g = nullptr;
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));
