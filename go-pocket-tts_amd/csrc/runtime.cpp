@@ -183,7 +183,7 @@ const float* Model::tcomb_for(int n) {
 // Batch
 // ------------------------------------------------------------------------------------------------
 Batch::~Batch() {
-    for (auto& row : graphs) for (hipGraphExec_t g : row) if (g) (void)hipGraphExecDestroy(g);
+    for (auto& set : graphs) for (auto& row : set) for (hipGraphExec_t g : row) if (g) (void)hipGraphExecDestroy(g);
     if (n_active_pinned) (void)hipHostFree(n_active_pinned);
     if (rows_pinned) (void)hipHostFree(rows_pinned);
 }
@@ -1023,20 +1023,21 @@ int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go
 // the batch).  Several steps per graph: the gap between two replays (~8 us of idle GPU) is paid once per graph.
 static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
     Model& m = *b.m;
-    if (b.graph_lsd != lsd || b.graph_noise != b.has_noise) {
-        for (auto& row : b.graphs) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    if (b.graph_lsd != lsd) {
+        for (auto& set : b.graphs) for (auto& row : set) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
         b.graph_lsd = lsd;
-        b.graph_noise = b.has_noise;
-        b.graph_steps[0] = b.graph_steps[1] = 0;
+        for (auto& gs : b.graph_steps) gs[0] = gs[1] = 0;
     }
-    // three columns: single steps, the short graphs (5 steps: batches that may end by EOS, and the tail of the others), the long ones (25).  A
-    // column is re-captured only when ITS step count changes (a call that alternates 25 / 5 / 1 keeps all three)
+    // two sets (a step with sampling noise reads its noise row: other launches), three columns each: single steps, the short graphs (5 steps:
+    // batches that may end by EOS, and the tail of the others), the long ones (25).  A column is re-captured only when ITS step count changes:
+    // calls that alternate temperatures, or 25 / 5 / 1 steps, keep their graphs
+    const int ns = b.has_noise ? 1 : 0;
     const int col = nsteps <= 1 ? 0 : nsteps <= 5 ? 1 : 2;
-    if (col > 0 && b.graph_steps[col - 1] != nsteps) {
-        for (auto& row : b.graphs) if (row[col]) { (void)hipGraphExecDestroy(row[col]); row[col] = nullptr; }
-        b.graph_steps[col - 1] = nsteps;
+    if (col > 0 && b.graph_steps[ns][col - 1] != nsteps) {
+        for (auto& row : b.graphs[ns]) if (row[col]) { (void)hipGraphExecDestroy(row[col]); row[col] = nullptr; }
+        b.graph_steps[ns][col - 1] = nsteps;
     }
-    hipGraphExec_t& slot = b.graphs[ni][col];
+    hipGraphExec_t& slot = b.graphs[ns][ni][col];
     if (slot) return slot;
     hipGraph_t g = nullptr;
     PTTS_HIP(hipStreamBeginCapture(m.stream, hipStreamCaptureModeThreadLocal));

@@ -119,10 +119,10 @@ struct Batch {
     bool capturing = false;
     // graph replay of the AR step (use_graph): one captured step per attention round count (attn_step_rounds: the step
     // attention's load rounds follow the cache length, and a captured launch cannot change), captured on first use
-    hipGraphExec_t graphs[17][3] = {};   // [attention rounds][0: one step, 1: graph_steps[0] steps (the short graphs), 2: graph_steps[1] steps (the long ones)]
-    int graph_steps[2] = {0, 0};   // steps per graph the second / third column was captured with
+    // [with sampling noise][attention rounds][0: one step, 1: graph_steps[.][0] steps (the short graphs), 2: graph_steps[.][1] steps (the long ones)]
+    hipGraphExec_t graphs[2][17][3] = {};
+    int graph_steps[2][2] = {{0, 0}, {0, 0}};   // steps per graph the second / third column was captured with
     int graph_lsd = 0;
-    bool graph_noise = false;
     int capture_keys = 0;    // while capturing: the cache-length bound the recorded attention launches must cover
     // page-locked scratch of the generate loop: [0] live-utterance count, [1, 1+B) n_frames, [1+B, 1+2B) eos_step read back in
     // one copy after the loop; rows_pinned: the B result rows uploaded to the decoder (no pageable staging, no extra sync)
