@@ -6,4 +6,4 @@ synth.py   synthetic checkpoints / voices / prompts (no real weights exist offli
 """
 from . import runtime, synth  # noqa: F401
 from .runtime import (Batch, Cancelled, DeviceVoice, Dispatcher, GenerateResult, Model, PttsError, Runtime, RuntimeGenerateConfig, Service, TTSConfig,  # noqa: F401
-                      VoiceEmbedding, VoiceModelState, KV_BF16, KV_F32, WEIGHTS_BF16, WEIGHTS_F32, WEIGHTS_INT8)
+                      VoiceEmbedding, VoiceFile, VoiceModelState, load_voice_conditioning, KV_BF16, KV_F32, WEIGHTS_BF16, WEIGHTS_F32, WEIGHTS_INT8)

@@ -412,6 +412,101 @@ void ptts_voice_free(ptts_voice* v) {
     delete vv;
 }
 
+// ---- voice files (voicefile.cpp) ----
+int ptts_voice_file_open(const char* path, ptts_voice_file** out) {
+    return guard([&] {
+        if (!path || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        *out = reinterpret_cast<ptts_voice_file*>(voice_file_from_path(path));
+    });
+}
+
+int ptts_voice_file_open_bytes(const void* data, size_t len, ptts_voice_file** out) {
+    return guard([&] {
+        if ((!data && len) || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        *out = reinterpret_cast<ptts_voice_file*>(voice_file_from_bytes(data, len));
+    });
+}
+
+void ptts_voice_file_close(ptts_voice_file* f) { delete reinterpret_cast<VoiceFile*>(f); }
+
+int32_t ptts_voice_file_kind(const ptts_voice_file* f) { return f ? reinterpret_cast<const VoiceFile*>(f)->kind : PTTS_VOICE_FILE_UNKNOWN; }
+
+int ptts_voice_file_embedding(const ptts_voice_file* f, const float** data, int64_t shape[3]) {
+    return guard([&] {
+        if (!f || !data || !shape) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        voice_file_embedding(*reinterpret_cast<const VoiceFile*>(f), data, shape);
+    });
+}
+
+int ptts_voice_file_modules(const ptts_voice_file* f, int32_t* n) {
+    return guard([&] {
+        if (!f || !n) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        const VoiceFile& v = *reinterpret_cast<const VoiceFile*>(f);
+        voice_file_require_state(v);
+        *n = (int32_t)v.modules.size();
+    });
+}
+
+int ptts_voice_file_module(const ptts_voice_file* f, int32_t i, const char** name, ptts_voice_tensor* cache, ptts_voice_tensor* offset) {
+    return guard([&] {
+        if (!f) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        const VoiceFile& v = *reinterpret_cast<const VoiceFile*>(f);
+        voice_file_require_state(v);
+        if (i < 0 || (size_t)i >= v.modules.size()) throw Error(PTTS_EINVAL, strfmt("ptts-hip: voice module index %d out of range [0,%zu)", i, v.modules.size()));
+        const VoiceFile::Module& m = v.modules[(size_t)i];
+        if (name) *name = m.name.c_str();
+        auto put = [&](const char* key, ptts_voice_tensor* o) {
+            if (!o) return;
+            std::memset(o, 0, sizeof *o);
+            auto it = m.tensors.find(key);
+            if (it == m.tensors.end()) return;
+            static const float none = 0.0f;
+            o->data = it->second.data.empty() ? &none : it->second.data.data();   // present but empty: data non-NULL, count 0
+            o->count = (int64_t)it->second.data.size();
+            o->rank = (int32_t)std::min<size_t>(it->second.shape.size(), 8);
+            for (int32_t d = 0; d < o->rank; d++) o->shape[d] = it->second.shape[(size_t)d];
+        };
+        put("cache", cache);
+        put("offset", offset);
+    });
+}
+
+int ptts_voice_file_state(const ptts_voice_file* f, int32_t n_layers, int32_t heads, int32_t head_dim, const float** caches, int64_t* steps, int64_t* offsets) {
+    return guard([&] {
+        if (!f) throw Error(PTTS_EINVAL, "native: voice model state is nil");
+        if (n_layers < 0 || (n_layers > 0 && (!caches || !steps || !offsets))) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        voice_file_state(*reinterpret_cast<const VoiceFile*>(f), n_layers, heads, head_dim, caches, steps, offsets);
+    });
+}
+
+static void voice_upload_from_file(ptts_model* h, const VoiceFile& vf, ptts_voice** out) {
+    Model& m = *h->m;
+    std::vector<const float*> caches((size_t)m.d.n_layers);
+    std::vector<int64_t> steps((size_t)m.d.n_layers), offs((size_t)m.d.n_layers);
+    voice_file_state(vf, m.d.n_layers, m.d.heads, m.d.hd, caches.data(), steps.data(), offs.data());
+    std::lock_guard<std::mutex> lock(m.mu);
+    m.use_device();
+    *out = reinterpret_cast<ptts_voice*>(voice_create(m, caches.data(), steps.data(), offs.data()));
+}
+
+int ptts_voice_open(ptts_model* h, const char* path, ptts_voice** out) {
+    return guard([&] {
+        if (!h || !h->m || !out) throw Error(PTTS_EINVAL, "native: model flow_lm unavailable");
+        if (!path) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::unique_ptr<VoiceFile> vf(voice_file_from_path(path));
+        voice_upload_from_file(h, *vf, out);
+    });
+}
+
+int ptts_voice_open_bytes(ptts_model* h, const void* data, size_t len, ptts_voice** out) {
+    return guard([&] {
+        if (!h || !h->m || !out) throw Error(PTTS_EINVAL, "native: model flow_lm unavailable");
+        if (!data && len) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::unique_ptr<VoiceFile> vf(voice_file_from_bytes(data, len));
+        voice_upload_from_file(h, *vf, out);
+    });
+}
+
 int ptts_profile_enable(ptts_model* h, int32_t on) {
     return guard([&] {
         if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");

@@ -215,6 +215,23 @@ size_t tokenizer_vocab(const Tokenizer& t);
 void tokenizer_free(Tokenizer* t);
 std::string nfkc_utf8(const std::string& s);
 
+// voice files (voicefile.cpp; internal/safetensors/reader.go:69-140,232-308, internal/native/flow_transformer.go:451-590): host only
+struct VoiceFile {
+    StFile st;
+    int kind = 0;                                        // PTTS_VOICE_FILE_*
+    std::vector<float> emb; std::vector<int64_t> emb_shape;   // LoadVoiceEmbedding: [1, T, D]
+    std::string emb_error;                               // why the first tensor is no embedding (1-D, 4-D ...)
+    struct Tensor { std::vector<int64_t> shape; std::vector<float> data; };
+    struct Module { std::string name; std::map<std::string, Tensor> tensors; };
+    std::vector<Module> modules;                         // LoadVoiceModelState: sorted by name; "current_end" already turned into "offset"
+    std::string state_error;
+};
+VoiceFile* voice_file_from_path(const std::string& path);
+VoiceFile* voice_file_from_bytes(const void* data, size_t len);
+void voice_file_embedding(const VoiceFile& v, const float** data, int64_t shape[3]);
+void voice_file_require_state(const VoiceFile& v);
+void voice_file_state(const VoiceFile& v, int n_layers, int heads, int head_dim, const float** caches, int64_t* steps, int64_t* offsets);
+
 // optional post-processing of a finished utterance (dsp.cpp; internal/audio/dsp.go)
 void dsp_peak_normalize(float* s, int64_t n);
 void dsp_dc_block(float* s, int64_t n, int sample_rate);

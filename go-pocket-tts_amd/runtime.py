@@ -81,6 +81,10 @@ _RESULT_DTYPE = np.dtype({"names": ["pcm", "n_samples", "latents", "n_frames", "
                                       _Result.eos_step.offset, _Result.status.offset, _Result.pcm16.offset, _Result.reserved.offset],
                           "itemsize": C.sizeof(_Result)})
 
+class _VoiceTensor(C.Structure):   # ptts_voice_tensor
+    _fields_ = [("data", C.POINTER(C.c_float)), ("count", C.c_int64), ("rank", C.c_int32), ("reserved", C.c_int32), ("shape", C.c_int64 * 8)]
+
+
 _lib = None
 
 # every symbol include/ptts.h declares (tests check that the built library exports all of them)
@@ -98,6 +102,8 @@ ABI_SYMBOLS = [
     "ptts_chunks_get", "ptts_chunks_free",
     "ptts_tokenizer_open", "ptts_tokenizer_open_bytes", "ptts_tokenizer_free", "ptts_tokenizer_vocab_size", "ptts_tokenizer_encode",
     "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast", "ptts_dsp_apply",
+    "ptts_voice_file_open", "ptts_voice_file_open_bytes", "ptts_voice_file_close", "ptts_voice_file_kind", "ptts_voice_file_embedding",
+    "ptts_voice_file_modules", "ptts_voice_file_module", "ptts_voice_file_state", "ptts_voice_open", "ptts_voice_open_bytes",
 ]
 
 
@@ -158,6 +164,18 @@ def lib():
         L.ptts_flow_direction.argtypes = [C.c_void_p, _FP, C.c_float, C.c_float, _FP, C.c_int32, _FP]
         L.ptts_voice_create.argtypes = [C.c_void_p, C.POINTER(_FP), _IP, _IP, C.POINTER(C.c_void_p)]
         L.ptts_voice_free.argtypes = [C.c_void_p]
+        L.ptts_voice_file_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ptts_voice_file_open_bytes.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ptts_voice_file_close.argtypes = [C.c_void_p]
+        L.ptts_voice_file_close.restype = None
+        L.ptts_voice_file_kind.argtypes = [C.c_void_p]
+        L.ptts_voice_file_kind.restype = C.c_int32
+        L.ptts_voice_file_embedding.argtypes = [C.c_void_p, C.POINTER(_FP), _IP]
+        L.ptts_voice_file_modules.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.ptts_voice_file_module.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_VoiceTensor), C.POINTER(_VoiceTensor)]
+        L.ptts_voice_file_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_FP), _IP, _IP]
+        L.ptts_voice_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
+        L.ptts_voice_open_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.ptts_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.ptts_profile_read.argtypes = [C.c_void_p, C.POINTER(_Profile)]
         L.ptts_op_linear.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int64, C.c_int64, _FP]
@@ -363,6 +381,17 @@ class Model:
         _check(lib().ptts_voice_create(self.h, ptrs, _ip(steps), _ip(offs), C.byref(h)))
         return DeviceVoice(h.value, int(offs[0]))
 
+    def open_voice(self, src) -> "DeviceVoice":
+        """A model-state voice file (path, or the file's bytes) straight into HBM: safetensors.LoadVoiceModelState +
+        initStateFromVoiceModelState + the upload (ptts_voice_open / ptts_voice_open_bytes)."""
+        h = C.c_void_p()
+        if isinstance(src, (bytes, bytearray, memoryview)):
+            buf = bytes(src)
+            _check(lib().ptts_voice_open_bytes(self.h, buf, len(buf), C.byref(h)))
+        else:
+            _check(lib().ptts_voice_open(self.h, os.fsencode(src), C.byref(h)))
+        return DeviceVoice(h.value, -1)
+
     def profile_enable(self, on):   # False / 0: off; True / 1: per-launch events + phases; 2: phases only
         _check(lib().ptts_profile_enable(self.h, int(on)))
 
@@ -536,6 +565,92 @@ class DeviceVoice:
             self.close()
         except Exception:  # noqa: BLE001
             pass
+
+
+VOICE_FILE_UNKNOWN, VOICE_FILE_EMBEDDING, VOICE_FILE_MODEL_STATE = 0, 1, 2
+VOICE_FILE_KIND_NAMES = {0: "unknown", 1: "embedding", 2: "model_state"}   # safetensors.VoiceFileKind (reader.go:20-26)
+
+
+class VoiceFile:
+    """A voice safetensors file read by the library (host only): InspectVoiceFile, LoadVoiceEmbedding, LoadVoiceModelState
+    (internal/safetensors/reader.go:69-155) over ptts_voice_file_*."""
+
+    def __init__(self, src):
+        self.h = C.c_void_p()
+        if isinstance(src, (bytes, bytearray, memoryview)):
+            buf = bytes(src)
+            _check(lib().ptts_voice_file_open_bytes(buf, len(buf), C.byref(self.h)))
+        else:
+            _check(lib().ptts_voice_file_open(os.fsencode(src), C.byref(self.h)))
+
+    @property
+    def kind(self) -> str:
+        return VOICE_FILE_KIND_NAMES[int(lib().ptts_voice_file_kind(self.h))]
+
+    def embedding(self) -> VoiceEmbedding:
+        p, shape = _FP(), np.zeros(3, np.int64)
+        _check(lib().ptts_voice_file_embedding(self.h, C.byref(p), _ip(shape)))
+        n = int(shape.prod())
+        data = np.ctypeslib.as_array(p, shape=(n,)).copy() if n else np.zeros(0, np.float32)
+        return VoiceEmbedding(data.reshape(tuple(int(x) for x in shape)), [int(x) for x in shape])
+
+    def model_state(self) -> VoiceModelState:
+        n = C.c_int32()
+        _check(lib().ptts_voice_file_modules(self.h, C.byref(n)))
+        mods = {}
+        for i in range(n.value):
+            name, cache, off = C.c_char_p(), _VoiceTensor(), _VoiceTensor()
+            _check(lib().ptts_voice_file_module(self.h, i, C.byref(name), C.byref(cache), C.byref(off)))
+            m = {}
+            for key, t in (("cache", cache), ("offset", off)):
+                if not t.data:
+                    continue
+                shape = tuple(int(t.shape[d]) for d in range(t.rank))
+                m[key] = (np.ctypeslib.as_array(t.data, shape=(int(t.count),)).copy() if t.count else np.zeros(0, np.float32)).reshape(shape)
+            mods[name.value.decode()] = m
+        return VoiceModelState(mods)
+
+    def state_arrays(self, n_layers: int, heads: int = 0, head_dim: int = 0):
+        """initStateFromVoiceModelState's checks (flow_transformer.go:451-590): per layer (cache [2,1,T,H,D], T, offset)."""
+        ptrs, steps, offs = (_FP * max(n_layers, 1))(), np.zeros(max(n_layers, 1), np.int64), np.zeros(max(n_layers, 1), np.int64)
+        _check(lib().ptts_voice_file_state(self.h, n_layers, heads, head_dim, ptrs, _ip(steps), _ip(offs)))
+        return ptrs, steps[:n_layers], offs[:n_layers]
+
+    def close(self):
+        if self.h:
+            lib().ptts_voice_file_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+def load_voice_conditioning(voice_path: str) -> dict:
+    """tts.loadVoiceConditioning (service.go:216-246): {} for a blank path, else the keyword RuntimeGenerateConfig takes
+    (voice_model_state or voice_embedding), chosen by the file's kind; error prefixes as in the reference."""
+    if not voice_path or not voice_path.strip():
+        return {}
+    try:
+        vf = VoiceFile(voice_path)
+    except PttsError as e:
+        raise PttsError(e.code, f"inspect voice safetensors: {e}") from None
+    try:
+        if vf.kind == "model_state":
+            try:
+                return {"voice_model_state": vf.model_state()}
+            except PttsError as e:
+                raise PttsError(e.code, f"load voice model state: {e}") from None
+        try:
+            return {"voice_embedding": vf.embedding()}
+        except PttsError as e:
+            raise PttsError(e.code, f"load voice embedding: {e}") from None
+    finally:
+        vf.close()
 
 
 def _voice_arrays(state: VoiceModelState, n_layers: int):

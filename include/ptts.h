@@ -266,6 +266,39 @@ void ptts_dispatcher_close(ptts_dispatcher* d);   /* waits for queued work; late
 int  ptts_voice_create(ptts_model* m, const float* const* caches, const int64_t* cache_steps, const int64_t* offsets, ptts_voice** out);
 void ptts_voice_free(ptts_voice* v);
 
+/* ---- voice FILES (internal/safetensors/reader.go:69-155,219-308).  The reference's Service reads the voice path of a request with
+ *      InspectVoiceFile and then either LoadVoiceModelState or LoadVoiceEmbedding (internal/tts/service.go:216-246); these entry points
+ *      are those three functions plus the consumer-side checks of flowTransformer.initStateFromVoiceModelState
+ *      (internal/native/flow_transformer.go:451-590).  Host only: no GPU is touched until ptts_voice_open uploads. ---- */
+#define PTTS_VOICE_FILE_UNKNOWN      0   /* VoiceFileUnknown */
+#define PTTS_VOICE_FILE_EMBEDDING    1   /* VoiceFileEmbedding: legacy `audio_prompt` (or any first tensor) [T, D] / [1, T, D] */
+#define PTTS_VOICE_FILE_MODEL_STATE  2   /* VoiceFileModelState: `<module>/cache` [2,B,T,H,D] + `<module>/offset` (or legacy `<module>/current_end`) */
+typedef struct ptts_voice_file ptts_voice_file;
+int  ptts_voice_file_open(const char* path, ptts_voice_file** out);                        /* OpenStore + classifyVoiceTensorNames + load */
+int  ptts_voice_file_open_bytes(const void* data, size_t len, ptts_voice_file** out);      /* ...FromBytes; the bytes are copied */
+void ptts_voice_file_close(ptts_voice_file* f);
+int32_t ptts_voice_file_kind(const ptts_voice_file* f);                                    /* InspectVoiceFile: PTTS_VOICE_FILE_* */
+/* LoadVoiceEmbedding (reader.go:69-85,219-230): the first tensor (sorted names) as [1, T, D]; *data stays owned by f and is what a
+ * request carries as voice_embedding (voice_frames = shape[1]; shape[2] must be the model's d_model).  PTTS_EFORMAT with the
+ * reference's message for a model-state file and for a tensor that is not 2-D or 3-D. */
+int  ptts_voice_file_embedding(const ptts_voice_file* f, const float** data, int64_t shape[3]);
+/* LoadVoiceModelState (reader.go:127-140,273-308) as the reference's map of modules: count, then per module its name and tensors
+ * ("cache", "offset"; a legacy `current_end` has already become offset = [float(len(current_end))], shape [1]).  PTTS_EFORMAT with the
+ * reference's message for an embedding file or a tensor name without "<module>/<key>". */
+typedef struct ptts_voice_tensor { const float* data; int64_t count; int32_t rank; int32_t reserved; int64_t shape[8]; } ptts_voice_tensor;
+int  ptts_voice_file_modules(const ptts_voice_file* f, int32_t* n_modules);
+int  ptts_voice_file_module(const ptts_voice_file* f, int32_t i, const char** name, ptts_voice_tensor* cache /* data NULL: absent */, ptts_voice_tensor* offset);
+/* initStateFromVoiceModelState (flow_transformer.go:451-480,517-590) up to the re-layout: for layers 0..n_layers-1 the module
+ * "transformer.layers.{i}.self_attn" must hold a cache [2,1,T,heads,head_dim] and an integral offset 0 <= offset <= T (heads /
+ * head_dim 0: unchecked, as a layer without them is in the reference).  Fills what ptts_request.voice_caches / voice_cache_steps /
+ * voice_offsets and ptts_voice_create take (pointers owned by f).  PTTS_EINVAL with the reference's messages. */
+int  ptts_voice_file_state(const ptts_voice_file* f, int32_t n_layers, int32_t heads, int32_t head_dim,
+                           const float** caches, int64_t* cache_steps, int64_t* offsets);
+/* a model-state voice file straight into HBM: ptts_voice_file_open[_bytes] + ptts_voice_file_state (the model's dimensions) +
+ * ptts_voice_create.  An embedding file answers PTTS_EFORMAT (LoadVoiceModelState's message): read it with ptts_voice_file_embedding. */
+int  ptts_voice_open(ptts_model* m, const char* path, ptts_voice** out);
+int  ptts_voice_open_bytes(ptts_model* m, const void* data, size_t len, ptts_voice** out);
+
 /* Measurement hook for bench.py: while enabled the AR step runs eagerly (no graph) with a HIP event pair around
  * every launch of the dominant (weight-streaming linear) kernel on the model's stream. */
 typedef struct ptts_profile {

@@ -454,6 +454,48 @@ def read_voice_offset(t: np.ndarray) -> int:
     return i
 
 
+def voice_state_layers(modules, n_layers: int, heads: int = 0, head_dim: int = 0):
+    """flowTransformer.initStateFromVoiceModelState up to the re-layout (flow_transformer.go:451-480): per layer
+    layerStateFromVoiceModule (:517-552) with readVoiceStateOffset (:554-566) and splitVoiceKVCache's shape checks (:568-590),
+    in the reference's order.  Returns (caches [2,B,T,H,D], steps, offsets); heads / head_dim 0 = unchecked (a layer without them)."""
+    if modules is None:
+        raise ValueError("native: voice model state is nil")
+    caches, steps, offs = [], [], []
+    for i in range(n_layers):
+        name = f"transformer.layers.{i}.self_attn"  # flow_transformer.go:513-515
+        mod = modules.get(name)
+        if mod is None:
+            raise ValueError(f'native: voice model state missing module "{name}"')
+        if "cache" not in mod:
+            raise ValueError(f'native: voice model state module "{name}" missing cache')
+        if "offset" not in mod:
+            raise ValueError(f'native: voice model state module "{name}" missing offset')
+        try:
+            off = read_voice_offset(np.asarray(mod["offset"], np.float32))
+        except ValueError as e:
+            raise ValueError(f'native: voice model state module "{name}" ' + str(e).replace("native: voice model state ", "")) from None
+        c = _f32(mod["cache"])
+        if c.ndim != 5:
+            raise ValueError(f'native: voice model state module "{name}" cache shape {list(c.shape)}, want [2,B,T,H,D]')
+        if c.shape[0] != 2:
+            raise ValueError(f'native: voice model state module "{name}" cache first dim {c.shape[0]}, want 2')
+        _, b, t, h, d = c.shape
+        if b <= 0 or h <= 0 or d <= 0:
+            raise ValueError(f'native: voice model state module "{name}" has invalid cache shape {list(c.shape)}')
+        if heads and h != heads:
+            raise ValueError(f'native: voice model state module "{name}" heads {h}, want {heads}')
+        if head_dim and d != head_dim:
+            raise ValueError(f'native: voice model state module "{name}" head dim {d}, want {head_dim}')
+        if off < 0:
+            raise ValueError(f'native: voice model state module "{name}" has negative offset {off}')
+        if off > t:
+            raise ValueError(f'native: voice model state module "{name}" offset {off} exceeds cache length {t}')
+        caches.append(c)
+        steps.append(t)
+        offs.append(off)
+    return caches, steps, offs
+
+
 # ---- model-level wrapper ----
 
 class OracleModel:
@@ -499,24 +541,7 @@ class OracleModel:
         return OracleState(self, lib().po_state_new(C.c_void_p(self.h)))
 
     def state_from_voice(self, modules: dict[str, dict[str, np.ndarray]]):
-        caches, steps, offs = [], [], []
-        for i in range(self.n_layers):
-            name = f"transformer.layers.{i}.self_attn"  # flow_transformer.go:513-515
-            mod = modules.get(name)
-            if mod is None:
-                raise ValueError(f'native: voice model state missing module "{name}"')
-            if "cache" not in mod:
-                raise ValueError(f'native: voice model state module "{name}" missing cache')
-            if "offset" not in mod:
-                raise ValueError(f'native: voice model state module "{name}" missing offset')
-            c = _f32(mod["cache"])
-            if c.ndim != 5 or c.shape[0] != 2:
-                raise ValueError(f'native: voice model state module "{name}" cache shape {list(c.shape)}, want [2,B,T,H,D]')
-            if c.shape[3] != self.heads or c.shape[4] != self.head_dim:
-                raise ValueError(f'native: voice model state module "{name}" heads/head dim mismatch')
-            caches.append(c)
-            steps.append(c.shape[2])
-            offs.append(read_voice_offset(mod["offset"]))
+        caches, steps, offs = voice_state_layers(modules, self.n_layers, self.heads, self.head_dim)
         ptrs = (_FP * self.n_layers)(*[_fp(c) for c in caches])
         st = np.array(steps, np.int64)
         of = np.array(offs, np.int64)

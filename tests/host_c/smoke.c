@@ -3,11 +3,13 @@
  * one GenerateAudio per chunk, internal/tts/runtime.go:42-45).  Plain C99 against include/ptts.h, linked with -lptts_hip, so the HIP
  * runtime it runs on is the system's /opt/rocm libamdhip64 (the library's own DT_NEEDED), not the copy PyTorch bundles.
  *
- *   smoke <checkpoint.safetensors> <case.bin> <out.bin>
+ *   smoke <checkpoint.safetensors> <case.bin> <out.bin> [voice.safetensors]
  *
  * case.bin (little endian), written by tests/test_gpu_c_host.py:
  *   int32 n_layers, T, H, D; int64 offsets[n_layers]; float caches[n_layers][2*T*H*D]      -- a voice model state
  *   int32 n_reqs; per request: int32 n_tokens, max_steps, use_voice; int64 tokens[n_tokens]
+ *     use_voice 0: none; 1: the arrays above in the request; 2: the voice FILE of argv[4], read and uploaded by the library itself
+ *     (ptts_voice_open: safetensors.LoadVoiceModelState + initStateFromVoiceModelState, reader.go:127-140, flow_transformer.go:451-480)
  * Calls: request 0 alone (n_reqs = 1 must reproduce GenerateAudio), then requests 1.. as ONE batched ptts_generate.
  * out.bin: per request int32 status, n_frames, eos_step, ldim; int64 n_samples; float pcm[n_samples]; float latents[n_frames*ldim]. */
 #include <stdio.h>
@@ -28,6 +30,8 @@ static void rd(void* dst, size_t n, FILE* f) {
 int main(int argc, char** argv) {
     ptts_opts opts;
     ptts_model* model = NULL;
+    ptts_voice* file_voice = NULL;
+    ptts_voice_file* vfile = NULL;
     ptts_info info;
     FILE* f;
     FILE* out;
@@ -41,11 +45,18 @@ int main(int argc, char** argv) {
     int64_t** toks;
     size_t per;
 
-    if (argc != 4) { fprintf(stderr, "usage: smoke checkpoint case.bin out.bin\n"); return 1; }
+    if (argc != 4 && argc != 5) { fprintf(stderr, "usage: smoke checkpoint case.bin out.bin [voice.safetensors]\n"); return 1; }
     ptts_default_opts(&opts);
     opts.device = 0;
     if (ptts_model_open(argv[1], &opts, &model) != PTTS_OK) die("ptts_model_open");
     if (ptts_model_info(model, &info) != PTTS_OK) die("ptts_model_info");
+    if (argc == 5) {
+        /* what tts.loadVoiceConditioning does with a voice path (service.go:216-246): inspect, then load by kind */
+        if (ptts_voice_file_open(argv[4], &vfile) != PTTS_OK) die("ptts_voice_file_open");
+        if (ptts_voice_file_kind(vfile) != PTTS_VOICE_FILE_MODEL_STATE) { fprintf(stderr, "smoke: voice file kind %d\n", (int)ptts_voice_file_kind(vfile)); return 1; }
+        ptts_voice_file_close(vfile);
+        if (ptts_voice_open(model, argv[4], &file_voice) != PTTS_OK) die("ptts_voice_open");
+    }
 
     f = fopen(argv[2], "rb");
     if (!f) { perror(argv[2]); return 1; }
@@ -80,7 +91,10 @@ int main(int argc, char** argv) {
         reqs[i].lsd_steps = 1;
         reqs[i].frames_after_eos = 3;
         reqs[i].want_latents = 1;
-        if (h3[2]) {
+        if (h3[2] == 2) {
+            if (!file_voice) { fprintf(stderr, "smoke: request %d wants the voice file, none given\n", (int)i); return 1; }
+            reqs[i].voice = file_voice;
+        } else if (h3[2]) {
             reqs[i].voice_caches = ccaches;
             reqs[i].voice_cache_steps = steps;
             reqs[i].voice_offsets = offsets;
@@ -105,6 +119,7 @@ int main(int argc, char** argv) {
         ptts_free_result(&res[i]);
     }
     fclose(out);
+    ptts_voice_free(file_voice);
     ptts_model_close(model);
     printf("smoke: %d requests, d_model %d, %d layers\n", (int)n_reqs, (int)info.d_model, (int)info.n_layers);
     return 0;

@@ -2,7 +2,8 @@
 libptts_hip.so and run as a child process with neither Python nor PyTorch in it -- the position of the reference's Go service behind
 cgo (internal/tts/service.go:39-98, runtime_native_safetensors.go:36-38).  Its HIP runtime is therefore the
 system's /opt/rocm libamdhip64 (the library's DT_NEEDED / RUNPATH), not the copy PyTorch bundles, which every ctypes test shares.
-One request alone (n_reqs = 1: the reference's GenerateAudio), then a batch of 8 (two of them on a voice model state); PCM, latents,
+One request alone (n_reqs = 1: the reference's GenerateAudio), then a batch of 8 (two of them on a voice model state passed as arrays,
+two on the same voice read from its FILE by the library: ptts_voice_file_open / ptts_voice_open); PCM, latents,
 frame counts against the oracle at the smoke tolerances of tests/test_gpu_model.py."""
 import os
 import shutil
@@ -60,7 +61,9 @@ def test_c_host_generates_audio_without_python_or_torch(pkg, tmp_path):
     rng = np.random.default_rng(5)
     reqs = [(np.array([10, 20, 30], np.int64), 3, 0)]
     for i in range(8):
-        reqs.append((rng.integers(0, cfg.n_bins, size=3 + i, dtype=np.int64), 2 + i % 3, 1 if i in (2, 5) else 0))
+        reqs.append((rng.integers(0, cfg.n_bins, size=3 + i, dtype=np.int64), 2 + i % 3, 1 if i in (2, 5) else 2 if i in (3, 7) else 0))
+    vpath = str(tmp_path / "voice.safetensors")          # the same voice as a FILE: requests 3 and 7 let the library read and upload it
+    synth.write_safetensors(vpath, voice)
     with open(tmp_path / "case.bin", "wb") as f:
         f.write(struct.pack("<4i", cfg.n_layers, T, H, D))
         f.write(np.array([int(mods[n]["offset"].reshape(-1)[0]) for n in names], np.int64).tobytes())
@@ -73,7 +76,7 @@ def test_c_host_generates_audio_without_python_or_torch(pkg, tmp_path):
     exe = build_host(tmp_path)
     # a clean child: no PYTHONPATH tricks, no preloaded HIP runtime; LD_LIBRARY_PATH is left as the box has it
     env = {k: v for k, v in os.environ.items() if not k.startswith("PTTS_")}
-    r = subprocess.run([exe, path, str(tmp_path / "case.bin"), str(tmp_path / "out.bin")], capture_output=True, text=True, env=env, timeout=300)
+    r = subprocess.run([exe, path, str(tmp_path / "case.bin"), str(tmp_path / "out.bin"), vpath], capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     maps = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
     assert "torch" not in maps, maps

@@ -344,6 +344,40 @@ def test_voice_model_state_with_nan_padding(pkg, tiny, legacy):
     parity("pcm (voice state)", got.pcm, ref["pcm"], MULTI_PCM_TOL)
 
 
+@pytest.mark.parametrize("legacy", [False, True])
+def test_voice_file_through_the_library(pkg, tiny, tmp_path, legacy):
+    """The voice as a FILE: ptts_voice_open (LoadVoiceModelState + initStateFromVoiceModelState + upload; reader.go:127-140,273-308,
+    flow_transformer.go:451-590) and ptts_voice_file_embedding (LoadVoiceEmbedding, reader.go:69-85) -- the same audio as the
+    in-memory routes and as the oracle reading the same file with its own restatement of the reader."""
+    cfg, _, om, gm = tiny
+    rt = pkg.Runtime(gm)
+    tens = pkg.synth.make_voice_state(cfg, offset=9, capacity=(9 if legacy else 16), legacy_current_end=legacy)
+    path = str(tmp_path / "voice.safetensors")
+    pkg.synth.write_safetensors(path, tens)
+    toks = [11, 12]
+    ref = om.generate(toks, max_steps=4, eos_threshold=1e30, frames_after_eos=3, voice_state=O.load_voice_model_state(O.Store.open(path)))
+    for src in (path, open(path, "rb").read()):
+        dv = gm.open_voice(src)
+        got = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=4, want_latents=True, device_voice=dv))
+        parity("latents (voice file -> device voice)", got.latents, ref["latents"], MULTI_LAT_TOL)
+        parity("pcm (voice file -> device voice)", got.pcm, ref["pcm"], MULTI_PCM_TOL)
+        dv.close()
+    kw = pkg.load_voice_conditioning(path)               # the Service's route: service.go:216-246
+    got2 = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=4, want_latents=True, **kw))
+    parity("latents (voice file -> model state)", got2.latents, ref["latents"], MULTI_LAT_TOL)
+    # an embedding file, and the refusal of each kind by the other loader
+    epath = str(tmp_path / "emb.safetensors")
+    pkg.synth.write_safetensors(epath, pkg.synth.make_voice_embedding(cfg, frames=7))
+    ve = O.load_voice_embedding(O.Store.open(epath))
+    ref_e = om.generate(toks, max_steps=4, eos_threshold=1e30, frames_after_eos=3, voice_emb=ve[0])
+    got_e = rt.generate(toks, pkg.RuntimeGenerateConfig(eos_threshold=float("inf"), max_steps=4, want_latents=True, **pkg.load_voice_conditioning(epath)))
+    parity("latents (voice file -> embedding)", got_e.latents, ref_e["latents"], MULTI_LAT_TOL)
+    with pytest.raises(pkg.PttsError, match='voice file kind "embedding" is not upstream model state'):
+        gm.open_voice(epath)
+    with pytest.raises(pkg.PttsError, match="contains upstream model state"):
+        pkg.VoiceFile(path).embedding()
+
+
 def test_voice_state_guards(pkg, tiny):
     cfg, _, om, gm = tiny
     b = gm.new_batch(1, 32)
