@@ -295,6 +295,7 @@ static void activate_ready(ContEngine& e, bool wait) {
         }
         launch_slot_admit(b.st, b.pre_len.as<int32_t>(), b.pre_k.as<const void*>(), b.pre_v.as<const void*>(), e.adm_dev[j.ring].as<SlotAdmit>(), (int)j.slots.size(),
                           e.m.stream);
+        b.opened = false;   // a newcomer's first input is BOS: the next step is opened by k_step_begin, not by the previous step's last launch
         for (int sl : j.slots) { e.slots[(size_t)sl].joining = false; e.slots[(size_t)sl].admit_seq = e.seq; e.slots[(size_t)sl].seen_seq = e.seq; }
         e.n_gen += (int)j.slots.size();
         e.free_events.push_back(j.ready);

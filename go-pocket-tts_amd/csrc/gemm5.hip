@@ -59,7 +59,10 @@ thread_local int g_gemm5_cfg = 0;   // debug knob (ptts_debug_gemm): 0 = default
 template <int BN, int NW, bool ELU_A, int ABL>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gemm5(GemmArgs a) {
     constexpr int BM = NW * 32, CH = 64, SPC = CH / 32, NTH = NW * 64, NT = BN / 16;
-    constexpr int HALF = BN * 64, STAGE = SPC * HALF;     // bytes: one [column][32 k] sub-chunk, one stage
+    // bytes: one [column][32 k] sub-chunk (+ 64 of padding: the two sub-chunks of a column are written by one ds_write_b128 service group of 8 lanes --
+    // four lanes each -- and at a distance of BN * 64 they sat on the SAME banks: a 2-way conflict on every weight store, which is what the
+    // SQ_LDS_BANK_CONFLICT counter showed for this kernel in round 3 while the fragment READS were conflict-free), one stage
+    constexpr int HALF = BN * 64 + 64, STAGE = SPC * HALF;
     constexpr int PPR = CH / 8, PIECES = BN * PPR, PPT = PIECES / NTH;
     static_assert(PIECES % NTH == 0, "whole 16-byte pieces per thread");
     __shared__ __attribute__((aligned(16))) char Ws[2 * STAGE];

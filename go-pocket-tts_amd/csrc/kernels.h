@@ -91,6 +91,10 @@ struct SkinnyFuse {
     // epilogue -- the frame is appended to the utterance's latents and the slot's counters advance.  One column block only
     // (N <= 64), so every reader of the counters in this launch has read them before the one lane per row that writes them.
     const StepFinish* fin = nullptr; // device memory
+    // with fin: the block also OPENS THE NEXT STEP (fin->ch): x = input_linear(frame, NaN -> bos), fx = input_proj(next noise row), x0 = that row --
+    // k_step_begin's work without its launch.  The frame then goes to the utterance's latents only (C is not written: it holds x0).
+    int chain = 0;
+    const float* chain_noise = nullptr; int64_t chain_noise_stride = 0;   // [B][max_steps][ldim] or null (zeros)
 };
 bool skinny_supported(const GemmArgs& a, int splitk);
 bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f);
@@ -238,6 +242,18 @@ bool resblock_up_supported(const ResArgs& a);
 void launch_resblock_up(const ResArgs& a, hipStream_t stream);
 
 
+// The feed-forward half of a Mimi decoder-transformer layer as one kernel (ffn_fused.hip): x += ls * linear2(gelu(linear1(LayerNorm(x)))),
+// rows of x updated in place; img: the per-chunk weight images of model.cpp add_ffn_image (bf16)
+struct FfnArgs {
+    float* x = nullptr; RowMap xmap;
+    const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+    const void* img = nullptr;
+    const float* ls = nullptr;      // [D] layer scale or null (1)
+    int M = 0, D = 0, F = 0;
+};
+bool mimi_ffn_supported(const FfnArgs& a);
+void launch_mimi_ffn(const FfnArgs& a, hipStream_t stream);
+
 // AR-step bookkeeping (runtime_native_safetensors.go:176-192 per slot, on device)
 struct StepState {
     int32_t* kv_len;        // [B] keys in the cache (== flowTransformerLayerState.offset)
@@ -252,12 +268,19 @@ struct StepState {
     int32_t* n_active;      // [1]
     int32_t* broke;         // [B] 1 when the loop left through the countdown `break` (no StepCallback for that step)
 };
+// the NEXT step's opening (what k_step_begin computes), for the step's last launch to carry (k_skinny FIN + CHAIN, step_open.h)
+struct StepChain {
+    const void* w_in; const float* b_in; float* x; int32_t d_in;      // input_linear [d_in][ldim] row-major -> x [B][d_in]
+    const void* w_pj; const float* b_pj; float* fx; int32_t d_pj;     // input_proj [d_pj][ldim] -> fx [B][d_pj]
+    const float* bos; float* x0; int32_t w_bf16; int32_t ok;          // x0: [B][ldim], the next step's noise row (or zeros); ok: the shapes fit (ldim == 32, ...)
+};
 struct StepFinish {         // arguments of k_step_finish, resident in device memory (Batch::fin_dev)
     StepState s;
     const float* eos_logit; // [B]
     float* latents;         // [B][lat_stride]
     int64_t lat_stride;
     int32_t ldim;
+    StepChain ch;
 };
 // prepares the step input: in32[b] = step==0 ? bos : latents[b][step-1] with NaN -> bos, x0[b] = noise of the step (or 0);
 // with `lin` also x = input_linear(in32) and fx = input_proj(x0) (the two ldim-wide linears of the step, exact f32)
@@ -266,6 +289,7 @@ struct StepOpenLinears {
     const void* w_pj = nullptr; const float* b_pj = nullptr; int d_pj = 0; float* fx = nullptr;    // [d_pj][ldim]
     int w_bf16 = 0;
 };
+bool step_open_mfma_ok(const StepOpenLinears& lin, int ldim);   // the matrix-core form (step_open.h) takes these shapes; it is the form a step's last launch can chain
 void launch_step_begin(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
                        int ldim, int b, float* in32, float* x0, const StepOpenLinears* lin, hipStream_t stream);
 // stores the decoded frame, applies EOS logic, advances kv_len/step

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include "kernels.h"
 #include "device_util.h"
+#include "step_open.h"
 
 namespace ptts {
 
@@ -823,8 +824,60 @@ __global__ __launch_bounds__(256) void k_step_begin(StepState s, const float* la
     if (first) x[(int64_t)bi * d_in + row] = acc;
     else fx[(int64_t)bi * d_pj + row] = acc;
 }
+// The same opening on the matrix core (step_open.h): a block = 16 rows x 64 columns of [x | fx].  Every block builds the bf16 hi / lo planes of its
+// rows' input frame and noise row (16 x 32 each), then each of its four waves multiplies one 16-column tile.  Same functions, same operand split as
+// the chained form in the step's last launch (skinny.hip): either way a step starts from the same bits.
+template <bool WBF16>
+__global__ __launch_bounds__(256) void k_step_begin_mm(StepState s, const float* latents, int64_t lat_stride, const float* noise, int64_t noise_stride, int b,
+                                                       float* in32, StepChain ch) {
+    __shared__ __attribute__((aligned(16))) unsigned char ih[16 * SO_PITCH], il[16 * SO_PITCH], nh[16 * SO_PITCH], nl[16 * SO_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * 16;
+    // the wave's weight fragment first: it does not depend on the step's input
+    int n0 = blockIdx.x * 64 + wave * 16;
+    const bool first = n0 < ch.d_in;
+    if (!first) n0 -= ch.d_in;
+    const bool have = first || n0 < ch.d_pj;
+    const SoW<WBF16> w = so_load_w<WBF16>(first ? ch.w_in : ch.w_pj, first ? ch.b_in : ch.b_pj, have ? n0 : 0, first ? ch.d_in : ch.d_pj, lane);
+    {
+        const int r = tid >> 4, c = (tid & 15) * 2, bi = m0 + r;   // 16 rows x 16 column pairs
+        float2 vi = make_float2(0.f, 0.f), vs = make_float2(0.f, 0.f);
+        if (bi < b) {
+            const int st = s.step[bi];
+            if (st == 0) vi = make_float2(NAN, NAN);
+            else vi = *reinterpret_cast<const float2*>(latents + (int64_t)bi * lat_stride + (int64_t)(st - 1) * SO_K + c);
+            if (isnan(vi.x)) vi.x = ch.bos[c];
+            if (isnan(vi.y)) vi.y = ch.bos[c + 1];
+            if (noise && st < s.max_steps[bi]) vs = *reinterpret_cast<const float2*>(noise + (int64_t)bi * noise_stride + (int64_t)st * SO_K + c);   // a finished utterance has no row `st`
+            if (blockIdx.x == 0) {
+                *reinterpret_cast<float2*>(in32 + (int64_t)bi * SO_K + c) = vi;
+                *reinterpret_cast<float2*>(ch.x0 + (int64_t)bi * SO_K + c) = vs;
+            }
+        }
+        so_put(ih, il, r, c, vi.x); so_put(ih, il, r, c + 1, vi.y);
+        so_put(nh, nl, r, c, vs.x); so_put(nh, nl, r, c + 1, vs.y);
+    }
+    __syncthreads();
+    if (!have) return;
+    if (first) so_tile<WBF16>(ih, il, w, n0, ch.x, ch.d_in, m0, b, lane);
+    else so_tile<WBF16>(nh, nl, w, n0, ch.fx, ch.d_pj, m0, b, lane);
+}
+
+bool step_open_mfma_ok(const StepOpenLinears& lin, int ldim) {
+    return ldim == SO_K && lin.d_in > 0 && lin.d_pj > 0 && lin.d_in % 16 == 0 && lin.d_pj % 16 == 0 && aligned16(lin.w_in) && aligned16(lin.w_pj) &&
+           (!lin.b_in || aligned16(lin.b_in)) && (!lin.b_pj || aligned16(lin.b_pj)) && aligned16(lin.x) && aligned16(lin.fx);
+}
+
 void launch_step_begin(const StepState& s, const float* latents, int64_t lat_stride, const float* bos, const float* noise, int64_t noise_stride,
                        int ldim, int b, float* in32, float* x0, const StepOpenLinears* lin, hipStream_t stream) {
+    if (lin && step_open_mfma_ok(*lin, ldim) && lat_stride % 2 == 0 && noise_stride % 2 == 0) {
+        StepChain ch{lin->w_in, lin->b_in, lin->x, lin->d_in, lin->w_pj, lin->b_pj, lin->fx, lin->d_pj, bos, x0, lin->w_bf16, 1};
+        dim3 grid((unsigned)((lin->d_in + lin->d_pj + 63) / 64), (unsigned)((b + 15) / 16));
+        note_launch("k_step_begin_mm");
+        if (lin->w_bf16) hipLaunchKernelGGL(k_step_begin_mm<true>, grid, dim3(256), 0, stream, s, latents, lat_stride, noise, noise_stride, b, in32, ch);
+        else hipLaunchKernelGGL(k_step_begin_mm<false>, grid, dim3(256), 0, stream, s, latents, lat_stride, noise, noise_stride, b, in32, ch);
+        return;
+    }
     const int cols = lin ? lin->d_in + lin->d_pj : 0;
     dim3 grid(lin ? (cols + 255) / 256 : 1, b);
     const void* w_in = lin ? lin->w_in : nullptr;

@@ -176,6 +176,46 @@ struct Walker {
                         if (lo) lo[e] = f32_to_bf16_rne(v - bf16_to_f32(h));
                     }
     }
+    // linear1 [F][512] and linear2 [512][F] of a Mimi transformer layer as the LDS images of k_mimi_ffn (ffn_fused.hip), bf16: per chunk c of 32 hidden
+    // units 64 KB that are copied to LDS as they are --
+    //   W1 image (32 KB): [k pair j (8)][hidden unit h (32)][128 B]; the 16-byte piece (k-step parity sg, lane group q) of row h sits at position
+    //     (4 sg + q) ^ ((h >> 1) & 7) and holds W1[32c + h][k] for k = 32 (2j + sg) + 4q + (0..3), then 32 (2j + sg) + 16 + 4q + (0..3);
+    //   W2 image (32 KB): [output o (512)][64 B]; lane group q's piece at position q ^ (3 ((o >> 3) & 1)) holds W2[o][32c + 4q + (0..3)], then
+    //     W2[o][32c + 16 + 4q + (0..3)].
+    // The positions make every ds_read_b128 fragment read conflict-free (16 lanes of a service group on 16 different 16-byte bank slots); the k order
+    // inside a piece is the order in which a pair of 16x16 accumulator tiles hands its values to the next product.
+    size_t add_ffn_image(const std::string& w1n, const std::string& w2n, int F) {
+        const int D = 512, nch = F / 32;
+        const size_t off = reserve((size_t)nch * 65536);
+        if (!host) return off;
+        const std::vector<float> w1 = load(w1n), w2 = load(w2n);
+        uint16_t* dst = reinterpret_cast<uint16_t*>(host + off);
+        for (int c = 0; c < nch; c++) {
+            uint16_t* i1 = dst + (size_t)c * 32768;          // (uint16 units: 64 KB per chunk)
+            uint16_t* i2 = i1 + 16384;
+            for (int j = 0; j < 8; j++)
+                for (int h = 0; h < 32; h++)
+                    for (int sg = 0; sg < 2; sg++)
+                        for (int q = 0; q < 4; q++) {
+                            const int pos = (4 * sg + q) ^ ((h >> 1) & 7), s = 2 * j + sg;
+                            uint16_t* p = i1 + ((size_t)j * 32 + h) * 64 + pos * 8;
+                            for (int e = 0; e < 8; e++) {
+                                const int k = 32 * s + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+                                p[e] = f32_to_bf16_rne(w1[(size_t)(32 * c + h) * D + k]);
+                            }
+                        }
+            for (int o = 0; o < D; o++)
+                for (int q = 0; q < 4; q++) {
+                    const int pos = q ^ (3 * ((o >> 3) & 1));
+                    uint16_t* p = i2 + (size_t)o * 32 + pos * 8;
+                    for (int e = 0; e < 8; e++) {
+                        const int hcol = 32 * c + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+                        p[e] = f32_to_bf16_rne(w2[(size_t)o * F + hcol]);
+                    }
+                }
+        }
+        return off;
+    }
     // the weights of a step linear as the kernels multiply them: the file's values, rounded to bf16 or int8-quantized per the mode
     std::vector<float> effective_weights(const std::string& wn) {
         std::vector<float> rm = load(wn);
@@ -496,6 +536,8 @@ struct Walker {
             if (has(p + ".layer_scale_1.scale")) L.ls1 = add_f32((size_t)f.at(p + ".layer_scale_1.scale").count(), [&](float* dst) { f.decode_f32(p + ".layer_scale_1.scale", dst); });
             if (has(p + ".layer_scale_2.scale")) L.ls2 = add_f32((size_t)f.at(p + ".layer_scale_2.scale").count(), [&](float* dst) { f.decode_f32(p + ".layer_scale_2.scale", dst); });
             if (L.out_proj.out % d.mimi_heads) throw Error(PTTS_EFORMAT, strfmt("native: mimi d_model %d not divisible by heads %d", L.out_proj.out, d.mimi_heads));
+            if (bf16w && L.l1.in == 512 && L.l2.out == 512 && L.l1.out == L.l2.in && L.l1.out % 32 == 0 && L.l1.b == NONE && L.l2.b == NONE)
+                L.ffn_img = add_ffn_image(p + ".linear1.weight", p + ".linear2.weight", L.l1.out);
             d.mimi_layers++;
         }
         if (d.mimi_layers == 0) throw Error(PTTS_EFORMAT, "native: no mimi decoder transformer layers found");

@@ -50,7 +50,10 @@ struct Desc {
     int mimi_dim = 0, mimi_heads = 8, mimi_hd = 0, mimi_layers = 0, mimi_ffn = 0, mimi_ctx = 250;
     int up_stride = 16, up_k = 32;
     size_t proj_w = NONE, proj_b = NONE, up_w0 = NONE, up_w1 = NONE;
-    struct ML { Norm n1, n2; Lin in_proj, out_proj, l1, l2; size_t ls1 = NONE, ls2 = NONE; } ml[MAX_LAYERS];
+    struct ML {
+        Norm n1, n2; Lin in_proj, out_proj, l1, l2; size_t ls1 = NONE, ls2 = NONE;
+        size_t ffn_img = NONE;   // linear1 / linear2 as the per-chunk LDS images of the fused feed-forward kernel (ffn_fused.hip; bf16 weights, width 512)
+    } ml[MAX_LAYERS];
     int sea_ch[4] = {0, 0, 0, 0};        // channels after initConv, up1, up2, up3
     int sea_hidden[3] = {0, 0, 0};
     int strides[3] = {6, 5, 4};          // mimi.go:582,592,602

@@ -188,6 +188,8 @@ Batch::~Batch() {
     if (rows_pinned) (void)hipHostFree(rows_pinned);
 }
 
+static bool open_linears(Batch& b, StepOpenLinears& lin);
+
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     if (n_slots <= 0) throw Error(PTTS_EINVAL, "ptts-hip: batch needs at least one slot");
     if (cap <= 0 || cap > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ptts-hip: kv capacity %d outside (0, %d] (RoPE table rows, flow_transformer.go:505)", cap, ROPE_SEQ));
@@ -227,9 +229,17 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     b->partial.ensure((size_t)16 * B * std::max(d.d_model, d.flow_dim) * f);
     b->latents.ensure(B * b->max_steps * d.ldim * f);
     {
-        StepFinish sf{b->st, b->eos.as<float>(), b->latents.as<float>(), (int64_t)b->max_steps * d.ldim, (int32_t)d.ldim};
-        b->fin_dev.ensure(sizeof sf);
-        h2d(b->fin_dev.p, &sf, sizeof sf, m.stream);
+        StepFinish sf{b->st, b->eos.as<float>(), b->latents.as<float>(), (int64_t)b->max_steps * d.ldim, (int32_t)d.ldim, StepChain{}};
+        StepOpenLinears lin;
+        b->chain_ok = open_linears(*b, lin) && step_open_mfma_ok(lin, d.ldim) && ((int64_t)b->max_steps * d.ldim) % 2 == 0 &&
+                      (lin.w_bf16 != 0) == (d.final_linear.bf16 != 0 || d.final_linear.wt_i8 != 0);   // the chained form takes the 32-deep linears' type from the step kernel's weight type
+        // two copies: a step that reads fx / cur (par 0) opens the next one in fx2 / cur2, and the other way round
+        b->fx2.ensure(B * d.flow_dim * f); b->cur2.ensure(B * d.ldim * f);
+        StepFinish sf2[2] = {sf, sf};
+        sf2[0].ch = StepChain{lin.w_in, lin.b_in, lin.x, lin.d_in, lin.w_pj, lin.b_pj, b->fx2.as<float>(), lin.d_pj, m.at<float>(d.bos), b->cur2.as<float>(), lin.w_bf16, b->chain_ok ? 1 : 0};
+        sf2[1].ch = StepChain{lin.w_in, lin.b_in, lin.x, lin.d_in, lin.w_pj, lin.b_pj, b->fx.as<float>(), lin.d_pj, m.at<float>(d.bos), b->cur.as<float>(), lin.w_bf16, b->chain_ok ? 1 : 0};
+        b->fin_dev.ensure(sizeof sf2);
+        h2d(b->fin_dev.p, sf2, sizeof sf2, m.stream);
     }
     PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(1 + 2 * B), hipHostMallocDefault));
     PTTS_HIP(hipHostMalloc((void**)&b->rows_pinned, sizeof(PcmRow) * std::max<size_t>((size_t)B, 1), hipHostMallocDefault));
@@ -238,6 +248,7 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
 }
 
 void batch_reset(Batch& b) {
+    b.opened = false;
     hipStream_t s = b.m->stream;
     const int B = b.B;
     launch_fill_i32(b.st.kv_len, 0, B, s);
@@ -522,11 +533,12 @@ struct FusedIn {
     const float* shift = nullptr; const float* scale = nullptr; int64_t ldmod = 0;
     float* y_out = nullptr;
     const StepFinish* finish = nullptr;   // the step's last launch: bookkeeping in the epilogue (SkinnyFuse::fin)
+    bool chain = false; const float* chain_noise = nullptr; int64_t chain_noise_stride = 0;   // ... and the next step's opening (SkinnyFuse::chain)
 };
 
 // returns whether in.finish was honoured (false: the caller launches k_step_finish itself)
 static bool step_fused_linear(Batch& b, const float* x, const FusedIn& in, const Lin& l, float* C, int64_t ldc, int M, int epi,
-                              const float* addvec, const float* R, float alpha, hipStream_t st = nullptr) {
+                              const float* addvec, const float* R, float alpha, hipStream_t st = nullptr, bool* chained = nullptr) {
     Model& m = *b.m;
     GemmArgs g = mk(m, x, flat(l.in), l, C, flat(ldc), M);
     g.epi = epi; g.addvec = addvec; g.R = R; g.alpha = alpha;
@@ -538,6 +550,11 @@ static bool step_fused_linear(Batch& b, const float* x, const FusedIn& in, const
     fu.shift = in.shift; fu.scale = in.scale; fu.ldmod = in.ldmod;
     fu.y_out = in.y_out;
     fu.fin = in.finish;
+    if (in.finish && in.chain) {
+        fu.chain = 1; fu.chain_noise = in.chain_noise; fu.chain_noise_stride = in.chain_noise_stride;
+        if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); if (chained) *chained = true; return true; }
+        fu.chain = 0; fu.chain_noise = nullptr;
+    }
     if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); return fu.fin != nullptr; }
     fu.fin = nullptr;
     if (skinny_fuse_supported(g, fu)) { step_gemm(m, g, fu, 1, nullptr, st); return false; }
@@ -566,25 +583,35 @@ static bool step_fused_linear(Batch& b, const float* x, const FusedIn& in, const
 // -> [LN2 + linear1 + GELU] -> [linear2, split over K]; the split-K sum and its residual add ride in the next
 // layer's first launch.  The residual stream ping-pongs between two buffers so that no launch reads rows another
 // block of the same launch rewrites.
+// the two ldim-wide linears at the head of a step, as the opening kernels take them; false: shapes they do not take (step_core then runs them as step linears)
+static bool open_linears(Batch& b, StepOpenLinears& lin) {
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    const int ld = d.ldim;
+    if (!(ld <= 64 && ld % 4 == 0 && d.input_linear.in == ld && d.input_proj.in == ld && d.input_linear.bf16 == d.input_proj.bf16)) return false;
+    lin.w_in = m.arena + d.input_linear.w; lin.b_in = m.at<float>(d.input_linear.b); lin.d_in = d.input_linear.out; lin.x = b.x.as<float>();
+    lin.w_pj = m.arena + d.input_proj.w; lin.b_pj = m.at<float>(d.input_proj.b); lin.d_pj = d.input_proj.out; lin.fx = b.fx.as<float>();
+    lin.w_bf16 = d.input_linear.bf16;
+    return true;
+}
+
 void step_open(Batch& b) {
     Model& m = *b.m;
     const Desc& d = m.d;
     const int ld = d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
     StepOpenLinears lin;
-    const bool ok = ld <= 64 && ld % 4 == 0 && d.input_linear.in == ld && d.input_proj.in == ld && d.input_linear.bf16 == d.input_proj.bf16;
-    if (ok) {
-        lin.w_in = m.arena + d.input_linear.w; lin.b_in = m.at<float>(d.input_linear.b); lin.d_in = d.input_linear.out; lin.x = b.x.as<float>();
-        lin.w_pj = m.arena + d.input_proj.w; lin.b_pj = m.at<float>(d.input_proj.b); lin.d_pj = d.input_proj.out; lin.fx = b.fx.as<float>();
-        lin.w_bf16 = d.input_linear.bf16;
-    }
+    const bool ok = open_linears(b, lin);
     b.opened = ok;
+    b.par = 0;   // k_step_begin writes the first pair (fx, cur)
     launch_step_begin(b.st, b.latents.as<float>(), ls, m.at<float>(d.bos), b.has_noise ? b.noise.as<float>() : nullptr, ls, ld, b.B,
                       b.in32.as<float>(), b.cur.as<float>(), ok ? &lin : nullptr, m.stream);
 }
 
-bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
+bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
     bool finished = false;
+    b.opened = false;   // x / fx are consumed by this step; a chained last launch (below) sets it again for the next one
+    if (!opened) b.par = 0;   // (the staged entry points and shapes k_step_begin does not take: the caller filled in32 / cur)
     Model& m = *b.m;
     const Desc& d = m.d;
     hipStream_t s = m.stream;
@@ -686,9 +713,9 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
     }
     // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
     float* ada = b.ada.as<float>();
-    float* fx = b.fx.as<float>();
+    float* fx = b.fx_now();
     float* fh2 = b.fh2.as<float>();
-    float* cur = b.cur.as<float>();
+    float* cur = b.cur_now();
     for (int i = 0; i < lsd; i++) {
         if (i > 0 || !tail_fused) {
             GemmArgs gc = mk(m, last, flat(D), d.cond_embed, sy, flat(C), B);  // sy = silu(0.5*(e_s+e_t) + cond_embed(c))
@@ -710,8 +737,17 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish) {
         FusedIn fin;  // flowFinalLayer.Forward flow_net.go:205-239: LayerNorm without affine, eps 1e-6, chunks: shift, scale
         fin.affine = false; fin.eps = 1e-6f;
         fin.shift = ada + (size_t)d.flow_depth * 3 * C; fin.scale = fin.shift + C; fin.ldmod = NA;
-        if (fuse_finish && i == lsd - 1) fin.finish = b.fin_dev.as<StepFinish>();
-        finished = step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd);  // current += flow / steps
+        if (fuse_finish && i == lsd - 1) {
+            fin.finish = b.fin_dev.as<StepFinish>() + b.par;
+            if (chain && b.chain_ok) {   // ... and the NEXT step's opening (k_step_begin's work without its launch)
+                fin.chain = true;
+                fin.chain_noise = b.has_noise ? b.noise.as<float>() : nullptr;
+                fin.chain_noise_stride = (int64_t)b.max_steps * d.ldim;
+            }
+        }
+        bool chained = false;
+        finished = step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd, nullptr, &chained);  // current += flow / steps
+        if (chained) { b.opened = true; b.par ^= 1; }
     }
     if (!b.capturing) b.kv_bound++;   // every live slot has appended one key
     return finished;
@@ -823,6 +859,16 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs go = mk(m, attn, flat(C), L.out_proj, upx, upm, R);
         go.R = upx; go.epi = L.ls1 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; go.scale = m.at<float>(L.ls1);
         launch_gemm(go, s);
+        if (L.ffn_img != NONE) {   // norm2 + linear1 + GELU + linear2 + layer scale + residual as one kernel (ffn_fused.hip)
+            FfnArgs fa;
+            fa.x = upx; fa.xmap = upm;
+            fa.ln_w = m.at<float>(L.n2.w); fa.ln_b = m.at<float>(L.n2.b); fa.eps = L.n2.eps;
+            fa.img = m.at<uint8_t>(L.ffn_img);
+            fa.ls = m.at<float>(L.ls2);
+            fa.M = R; fa.D = C; fa.F = F;
+            static const int want = [] { const char* e = getenv("PTTS_FFN_FUSED"); return e ? atoi(e) : 1; }();   // A/B measurement
+            if (want && mimi_ffn_supported(fa)) { launch_mimi_ffn(fa, s); continue; }
+        }
         launch_layernorm(mkln(m, upx, upm, L.n2, n1, C, R), s);
         GemmArgs g1 = mk(m, n1, flat(C), L.l1, ffb, flat(F), R);
         g1.epi = EPI_GELU;
@@ -1019,6 +1065,11 @@ int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go
     return ms;
 }
 
+static bool chain_steps() {
+    static const bool on = [] { const char* e = getenv("PTTS_CHAIN_OPEN"); return !e || atoi(e) != 0; }();   // A/B measurement (0: k_step_begin in front of every step)
+    return on;
+}
+
 // the graph of `nsteps` consecutive AR steps whose attention launches cover `ni` load rounds (captured on first use, kept with
 // the batch).  Several steps per graph: the gap between two replays (~8 us of idle GPU) is paid once per graph.
 static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
@@ -1046,13 +1097,17 @@ static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
     try {
+        // a graph opens its first step with k_step_begin (slots may have changed since the last one); inside, every step's last launch opens the next
+        b.opened = false;
         for (int k = 0; k < nsteps; k++) {
-            step_open(b);
-            if (!step_core(b, lsd, b.opened, true))
-                launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+            if (!b.opened) step_open(b);
+            if (!step_core(b, lsd, b.opened, true, chain_steps() && k + 1 < nsteps))
+                launch_step_finish(b.st, b.cur_now(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
         }
+        b.opened = false;
     } catch (...) {
         b.capturing = false;
+        b.opened = false;
         (void)hipStreamEndCapture(m.stream, &g);
         if (g) (void)hipGraphDestroy(g);
         throw;
@@ -1072,14 +1127,17 @@ void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps) {
         const int ni = attn_step_rounds(std::min(b.kv_bound + nsteps, b.cap), m.opts.kv == PTTS_KV_BF16);
         PTTS_HIP(hipGraphLaunch(step_graph(b, lsd, ni, nsteps), m.stream));
         b.kv_bound += nsteps;
+        b.opened = false;   // (a graph ends unchained)
         return;
     }
     const int ld = m.d.ldim;
     const int64_t ls = (int64_t)b.max_steps * ld;
-    step_open(b);
+    // plain launches: the previous step's last launch normally opened this one (b.opened); whoever changes a slot between two steps
+    // (batch_reset, admission of a newcomer, the staged API) clears the flag, and k_step_begin opens the step for every row
+    if (!b.opened) step_open(b);
     static const bool fuse = [] { const char* e = getenv("PTTS_FUSE_FINISH"); return !e || atoi(e) != 0; }();   // A/B measurement
-    if (!step_core(b, lsd, b.opened, fuse))   // the bookkeeping normally rides in the step's last launch
-        launch_step_finish(b.st, b.cur.as<float>(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
+    if (!step_core(b, lsd, b.opened, fuse, fuse && chain_steps()))   // the bookkeeping normally rides in the step's last launch
+        launch_step_finish(b.st, b.cur_now(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
 }
 
 static void fail_req(ptts_result& r, int code) {

@@ -109,7 +109,14 @@ struct Batch {
     DevBuf latents;          // [B][max_steps][ldim]
     DevBuf noise;            // [B][max_steps][ldim] or empty
     bool has_noise = false;
-    bool opened = false;     // the last step_open also produced x and fx
+    bool opened = false;     // x and fx of the COMING step are in place: set by step_open and by a step whose last launch chained the next one's opening
+    bool chain_ok = false;   // the shapes allow that chaining (StepFinish::ch in fin_dev)
+    // a chained launch runs several blocks per row tile, so what it writes for the next step (fx, x0) must not be what its other blocks still read:
+    // fx / cur alternate with fx2 / cur2 from one chained step to the next (par: which pair the coming step reads; 0 after every k_step_begin)
+    DevBuf fx2, cur2;
+    int par = 0;
+    float* fx_now() const { return (par ? fx2 : fx).as<float>(); }
+    float* cur_now() const { return (par ? cur2 : cur).as<float>(); }
     hipStream_t io_stream = nullptr;   // continuous batch: voice ingestion and prefill of newcomers run here, beside the step chain on the model's stream
     bool slot_local = false; // continuous batch: per-slot device state (kv_len, voice prefix) is written slot by slot by the admit kernel, never as whole arrays
     // host-side upper bound on the cache length of any slot (set by voice/prompt ingestion, +1 per step): lets a step's
@@ -176,7 +183,8 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 // core of one AR step on device state: in32 [B, ldim], cur [B, ldim] (= x0) -> cur (= frame), eos, last; appends KV at kv_len
 // opened: x and fx were produced by step_open; fuse_finish: the bookkeeping of k_step_finish rides in the last launch -- returns
 // whether it did (false: the caller launches k_step_finish)
-bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = false);
+// chain (with fuse_finish): the last launch also opens the next step (sets b.opened); the frame then lives in the latents only, b.cur holds the next x0
+bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = false, bool chain = false);
 void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 // xformer_out (optional, staged parity checks): the decoder transformer's output rows [B][T * up_stride][mimi_dim]
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev, float* xformer_out = nullptr);

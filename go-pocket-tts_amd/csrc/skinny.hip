@@ -5,6 +5,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "device_util.h"
+#include "step_open.h"
 
 namespace ptts {
 
@@ -38,6 +39,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+constexpr int SK_CHAIN_BX = 3;  // blocks per row tile of a chained last launch: one for fx and the books, two for the halves of x (1024 columns)
 constexpr int SK_KMAX = 1024;   // K slice per block (LDS image: 2 x 16 rows x 2 KB = 64 KB)
 constexpr int SK_KMAX2 = 2048;  // ... for the plain (no fused prologue) split-K launches: NJ = 8, image 2 x 16 rows x 4 KB = 128 KB
 
@@ -68,7 +70,8 @@ constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_ONE 
 // not hold its eight registers (the fused-prologue variants sit at the 128-register limit of a 16-wave block)
 // WT: how the weights are stored -- 0: f32, 1: bf16, 2: per-row-scaled int8 (offset-binary bytes; converted to bf16 in registers,
 // which is exact for [-127, 127]; the row scale is applied to the sums in the epilogue)
-template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false>
+// CHAIN (with FIN): the block also opens the NEXT step -- see SkinnyFuse::chain and step_open.h
+template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false, bool CHAIN = false>
 __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_ms, int p_n, int p_k, const float* p_part, const float* p_lnw,
                                                  const float* p_lnb, GemmArgs a, SkinnyFuse fu, float* partial, unsigned long long* stamps) {
     // The nine leading scalars -- copies of a.Wt, a.A, a.amap.ld, a.M | split << 8, a.N, a.K, fu.partial, fu.ln_w, fu.ln_b: 14 dwords, all
@@ -95,7 +98,10 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches
     constexpr int KP = 16 / CG;                // K parts per column group
     const int cg = wave % CG, kq4 = wave / CG;
-    const int n = blockIdx.x * (16 * CG) + cg * 16 + (lane & 15);
+    // (a chained launch runs SK_CHAIN_BX blocks per row tile that all compute the one column block of the frame -- same instructions, same bits -- and
+    // share out the next step's opening: block 0 keeps the books, stores the frame and computes fx, the others the columns of x)
+    const int cbx = CHAIN ? 0 : blockIdx.x;
+    const int n = cbx * (16 * CG) + cg * 16 + (lane & 15);
     const int m0 = blockIdx.y * 16, z = blockIdx.z, q = lane >> 4;
     const bool n_ok = n < p_n;
     const int kper = splitk > 1 ? ((p_k + splitk - 1) / splitk + 127) / 128 * 128 : p_k;
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     uint4 w[NTW][WV];
     {
         const int nss_all = (p_k + 127) >> 7;
-        const int tile = blockIdx.x * CG + cg, ss_base = k_begin >> 7;
+        const int tile = cbx * CG + cg, ss_base = k_begin >> 7;
         const bool tile_ok = tile * 16 < p_n;
 #pragma unroll
         for (int t = 0; t < NTW; t++) {
@@ -162,6 +168,32 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 #pragma unroll
             for (int s = 0; s < WV; s++) w[t][s] = src[s * 64];
         }
+    }
+    // chained opening of the next step: this wave's weight fragments (and bias pieces) of the two 32-deep linears go out right behind
+    // the step weights -- they depend on nothing the step computes, and the four blocks of this launch have nobody to hide a late
+    // request behind (a first cut that requested them after the products lost 5 us per step: three dependent cold round trips at the tail)
+    constexpr int CT = 2;               // 16-column tiles per wave and pass: block 0 covers 16 x 2 x 16 = 512 columns of fx, blocks 1.. 512 columns of x each
+    constexpr bool CWB = WT != 0;       // the 32-deep linears are bf16 whenever the step weights are not f32 (host: StepChain::w_bf16)
+    [[maybe_unused]] SoW<CWB> cw[CHAIN ? CT : 1];
+    [[maybe_unused]] float2 c_vs = make_float2(0.f, 0.f);
+    [[maybe_unused]] const bool c_fx = blockIdx.x == 0;                           // this block's share: fx, or a slice of x
+    [[maybe_unused]] const int c_t0 = c_fx ? 0 : ((int)blockIdx.x - 1) * 16 * CT;   // its first 16-column tile
+    // what the tail needs of the chain record, held from here on: a second look at fu.fin->ch behind the block's barriers would be a fresh (cold) scalar
+    // round trip on the tail of a launch that has nothing to hide it behind -- and so would the bos vector
+    [[maybe_unused]] float* c_out = nullptr; [[maybe_unused]] float* c_x0 = nullptr;
+    [[maybe_unused]] const void* c_wp = nullptr; [[maybe_unused]] const float* c_bp = nullptr;
+    [[maybe_unused]] int c_n = 0;
+    [[maybe_unused]] float c_bos = 0.f;
+    if constexpr (CHAIN) {
+        const StepChain& ch = fu.fin->ch;
+        c_wp = c_fx ? ch.w_pj : ch.w_in;
+        c_bp = c_fx ? ch.b_pj : ch.b_in;
+        c_n = c_fx ? ch.d_pj : ch.d_in;
+        c_out = c_fx ? ch.fx : ch.x;
+        c_x0 = ch.x0;
+#pragma unroll
+        for (int t = 0; t < CT; t++) cw[t] = so_load_w<CWB>(c_wp, c_bp, min((c_t0 + wave * CT + t) * 16, c_n - 16), c_n, lane);
+        c_bos = ch.bos[min(n, SO_K - 1)];
     }
     __builtin_amdgcn_sched_barrier(0);   // rows, then weights, then everything that needs the argument block
     SK_STAMP(1);
@@ -341,6 +373,20 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         }
     }
 
+    // chained opening of the next step: waves 4..11 stage the next noise row (thread -> row, column pair); the row's counters are read
+    // here, before the block's next barrier, like the bookkeeping lanes' -- the lane that advances them writes after the last one
+    int c_st = 0, c_max = 0, c_act = 0;
+    [[maybe_unused]] const int c_e = tid - 256, c_r = (c_e >> 4) & 15, c_c = (c_e & 15) * 2;
+    [[maybe_unused]] const bool c_noise = CHAIN && blockIdx.x == 0 && tid >= 256 && tid < 512;
+    if constexpr (CHAIN) {
+        if (c_noise && fu.chain_noise && m0 + c_r < p_m) {
+            const StepState& fs = fu.fin->s;
+            c_st = fs.step[m0 + c_r];
+            c_max = fs.max_steps[m0 + c_r];
+            c_act = fs.active[m0 + c_r];
+        }
+    }
+
     f32x4 acc_h = {0.f, 0.f, 0.f, 0.f}, acc_l = {0.f, 0.f, 0.f, 0.f};
     const int i16 = lane & 15;
 #pragma unroll
@@ -395,10 +441,18 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     const f32x4 accv = acc_h + acc_l;
     if (kq4 > 0) red[((kq4 - 1) * CG + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
     if constexpr (FIN) asm volatile("" ::"v"(f_act[0]), "v"(f_act[1]), "v"(f_act[2]), "v"(f_act[3]), "v"(f_step[0]), "v"(f_step[1]), "v"(f_step[2]), "v"(f_step[3]));
+    if constexpr (CHAIN) {   // the next step's noise row (the counters it hangs on were requested before the products)
+        if (c_noise && fu.chain_noise && m0 + c_r < p_m && c_act && c_st + 1 < c_max)
+            c_vs = *reinterpret_cast<const float2*>(fu.chain_noise + (int64_t)(m0 + c_r) * fu.chain_noise_stride + (int64_t)(c_st + 1) * SO_K + c_c);
+    }
     __syncthreads();
     SK_STAMP(5);
-    if (kq4 > 0) return;
-    if (!n_ok) return;
+    if constexpr (!CHAIN) {
+        if (kq4 > 0) return;
+        if (!n_ok) return;
+    }
+    __shared__ __attribute__((aligned(16))) unsigned char c_planes[CHAIN ? 4 * 16 * SO_PITCH : 16];   // frame hi / lo, noise hi / lo
+    if (!CHAIN || (kq4 == 0 && n_ok)) {
     float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
 #pragma unroll
     for (int t = 1; t < KP; t++) {
@@ -459,18 +513,22 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             for (int reg = 0; reg < 4; reg++) v[reg] = to_tail ? v[reg] : elu1(e_r[reg] + v[reg]);
             break;
     }
-    float* const cbase = to_tail ? a.tail : a.C;
+    float* const cbase = CHAIN ? nullptr : (to_tail ? a.tail : a.C);   // chained: C (the Euler state) receives the next step's x0 below, the frame goes to the latents
     const int64_t cld = to_tail ? 1 : a.cmap.ld;
     const int ccol = to_tail ? 0 : n;
+    if constexpr (CHAIN) {   // the frame as the next step's input: NaN -> bos (tensor_util.go:259-268), bf16 hi / lo planes [16][32]
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) so_put(c_planes, c_planes + 16 * SO_PITCH, q * 4 + reg, n, isnan(v[reg]) ? c_bos : v[reg]);
+    }
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {
         const int m = m0 + q * 4 + reg;
         if (m < p_m && cbase) cbase[(int64_t)m * cld + ccol] = v[reg];
         if constexpr (FIN)
-            if (m < p_m && !to_tail && f_act[reg]) fu.fin->latents[(int64_t)m * fu.fin->lat_stride + (int64_t)f_step[reg] * fu.fin->ldim + n] = v[reg];   // latentFrames = append(...)
+            if (m < p_m && !to_tail && f_act[reg] && (!CHAIN || blockIdx.x == 0)) fu.fin->latents[(int64_t)m * fu.fin->lat_stride + (int64_t)f_step[reg] * fu.fin->ldim + n] = v[reg];   // latentFrames = append(...)
     }
     if constexpr (FIN)
-    if (cg == 0 && (lane & 15) == 0) {   // k_step_finish's bookkeeping (runtime_native_safetensors.go:176-192), one lane per row
+    if (cg == 0 && (lane & 15) == 0 && (!CHAIN || blockIdx.x == 0)) {   // k_step_finish's bookkeeping (runtime_native_safetensors.go:176-192), one lane per row
         const StepState& fs = fu.fin->s;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
@@ -494,6 +552,28 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
         }
     }
     if (STAMP) { SK_STAMP(2); __builtin_amdgcn_s_waitcnt(0); SK_STAMP(6); }   // stores issued; stores acknowledged
+    }   // (the storing waves)
+    if constexpr (CHAIN) {
+        unsigned char* const fh = c_planes, * const fl = c_planes + 16 * SO_PITCH, * const nh = c_planes + 32 * SO_PITCH, * const nl = c_planes + 48 * SO_PITCH;
+        if (c_noise) {
+            so_put(nh, nl, c_r, c_c, c_vs.x);
+            so_put(nh, nl, c_r, c_c + 1, c_vs.y);
+        }
+        __syncthreads();   // planes complete; every read of this step's x0 (the Euler update's residual) has been consumed
+        if (c_noise && m0 + c_r < p_m) *reinterpret_cast<float2*>(c_x0 + (int64_t)(m0 + c_r) * SO_K + c_c) = c_vs;
+        const unsigned char* const ph = c_fx ? nh : fh, * const pl = c_fx ? nl : fl;
+        // block 0: every column of fx; block j > 0: columns [(j-1) 512, j 512) of x, then -- a launch with fewer blocks than x has slices -- every gridDim.x-1-th slice after it
+        const int stride_t = c_fx ? 16 * CT : ((int)gridDim.x - 1) * 16 * CT;
+        for (int tb = c_t0; tb * 16 < c_n; tb += stride_t) {   // (one pass at the model's widths)
+#pragma unroll
+            for (int t = 0; t < CT; t++) {
+                const int n0 = (tb + wave * CT + t) * 16;
+                if (n0 >= c_n) break;
+                const SoW<CWB> w = tb == c_t0 ? cw[t] : so_load_w<CWB>(c_wp, c_bp, n0, c_n, lane);
+                so_tile<CWB>(ph, pl, w, n0, c_out, c_n, m0, p_m, lane);
+            }
+        }
+    }
 #undef SK_STAMP
 }
 
@@ -508,7 +588,8 @@ bool skinny_fuse_supported(const GemmArgs& a, const SkinnyFuse& f) {
     // the fused prologue needs whole rows in one block: K is the row width, one K slice, dense rows
     return skinny_supported(a, 1) && a.K <= SK_KMAX && a.amap.ld == a.K && a.K % 4 == 0 && (!f.scale || f.ldmod % 4 == 0) &&
            !f.pgate && (!f.ln_w == !f.ln_b) && (!f.partial || f.psplit >= 1) && (f.ln || !(f.ln_w || f.scale)) &&
-           (!f.fin || (a.N <= 64 && a.K <= 512 && f.ln && f.scale && !f.ln_w && !f.partial));   // fin: instantiated for the flow net's final layer only
+           (!f.fin || (a.N <= 64 && a.K <= 512 && f.ln && f.scale && !f.ln_w && !f.partial)) &&   // fin: instantiated for the flow net's final layer only
+           (!f.chain || (f.fin && a.N == SO_K && a.epi == EPI_AXPY && !a.tail && f.chain_noise_stride % 2 == 0));   // chain: the frame is the whole row of C (ldim == 32)
 }
 
 thread_local hipEvent_t g_skinny_ev[2] = {nullptr, nullptr};   // measurement pass (bench.py roofline): the kernel's own begin / end timestamps
@@ -519,6 +600,15 @@ template <int WBF16, int PRO, int NJ, int CG>
 static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, hipStream_t stream) {
     dim3 grid((a.N + 16 * CG - 1) / (16 * CG), (a.M + 15) / 16, splitk);
     if constexpr (PRO == (PRO_LN | PRO_MOD) && NJ == 2 && CG == 4) {
+        if (fu.fin && fu.chain) {   // ... which also opens the next step: SK_CHAIN_BX blocks per row tile (k_skinny, `cbx`)
+            grid.x = SK_CHAIN_BX;
+            if (g_skinny_ev[0])
+                hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld,
+                                      a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
+            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
+                                    (unsigned long long*)nullptr);
+            return;
+        }
         if (fu.fin) {   // the flow net's final layer with the step's bookkeeping in its epilogue (one column block: grid.x == 1)
             if (g_skinny_ev[0])
                 hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld,

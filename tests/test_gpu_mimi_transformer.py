@@ -87,10 +87,10 @@ def test_a_wrong_window_would_fail(pkg, mimi_full):
     assert abs_bad > 10 * XF_TOL[0] * max(1.0, scale) or rel_bad > 10 * XF_TOL[1], (abs_bad, rel_bad, scale)
 
 
-def test_wide_batch_takes_the_weights_resident_gemm(pkg, mimi_full):
-    """16 utterances x 64 frames = 16384 rows: with bf16 weights linear1 (512 -> 2048, GELU) runs as k_gemm_wres<128,512>, the
-    kernel the 64-utterance benchmark uses for it (f32 weights keep k_gemm3: the resident-weights kernel holds bf16 tiles).
-    Three of the utterances are held against the oracle (all 1024 rows each)."""
+def test_wide_batch_takes_the_fused_feed_forward(pkg, mimi_full):
+    """16 utterances x 64 frames = 16384 rows: with bf16 weights norm2 + linear1 (512 -> 2048, GELU) + linear2 + layer scale + residual of each
+    layer run as ONE k_mimi_ffn launch (ffn_fused.hip), the kernel the 64-utterance benchmark uses (f32 weights keep the LayerNorm launch and
+    k_gemm3: the fused kernel holds bf16 weight images).  Three of the utterances are held against the oracle (all 1024 rows each)."""
     dtype, om, gm = mimi_full
     rng = np.random.default_rng(11)
     x = lat(rng, 16, 64)
@@ -99,7 +99,7 @@ def test_wide_batch_takes_the_weights_resident_gemm(pkg, mimi_full):
     counts = pkg.runtime.launch_counts(False)
     rope = "k_gemm5+rope" if dtype == "BF16" else "k_gemm3+rope"       # k_gemm5 takes bf16 weights from 1024 rows
     assert counts.get("k_attn_window", 0) == 2 and counts.get(rope, 0) == 2, counts
-    assert (counts.get("k_gemm_wres<128,512>", 0) >= 2) == (dtype == "BF16"), counts
+    assert counts.get("k_mimi_ffn", 0) == (2 if dtype == "BF16" else 0), counts
     for u in (0, 7, 15):
         want = om.mimi_transformer(om.latent_to_mimi(x[u]))
         parity(f"a17 transformer_out {dtype} batch16 rows=1024 [{u}]", xf[u], want, XF_TOL, rel_floor=XF_FLOOR)
@@ -152,10 +152,11 @@ def test_wide_batch_is_bit_reproducible_and_slot_symmetric(pkg, mimi_full):
 
 
 def test_wide_batch_equals_the_single_utterance_path_bit_for_bit(pkg, mimi_full):
-    """16 utterances x 64 frames (16384 rows: k_gemm5 in 256-row tiles and k_gemm_wres with bf16 weights) against the first 48 frames of one
-    utterance alone (768 rows: k_gemm3; every op of the decoder is causal, so those rows do not depend on the later frames): the many-row
-    kernels keep one k order, the same bf16 hi + lo halves and the same epilogue rounding (no contraction), so the transformer's output
-    must be the same BITS whatever the batch and whichever kernel -- the property the slot-symmetry test needs at full size."""
+    """16 utterances x 64 frames (16384 rows: k_gemm5 in 256-row tiles, the fused feed-forward kernel with bf16 weights) against the first 48 frames
+    of one utterance alone (768 rows: k_gemm3 for the projections, the same fused kernel for the feed-forward; every op of the decoder is causal,
+    so those rows do not depend on the later frames): the many-row kernels keep one k order, the same bf16 hi + lo halves and the same epilogue
+    rounding (no contraction), so the transformer's output must be the same BITS whatever the batch and whichever kernel -- the property the
+    slot-symmetry test needs at full size."""
     dtype, om, gm = mimi_full
     rng = np.random.default_rng(11)
     x = lat(rng, 16, 64)
@@ -163,7 +164,7 @@ def test_wide_batch_equals_the_single_utterance_path_bit_for_bit(pkg, mimi_full)
     _, _, xf = gm.decode_stages(x)
     counts = pkg.runtime.launch_counts(False)
     if dtype == "BF16":
-        assert counts.get("k_gemm5+rope", 0) == 2 and counts.get("k_gemm_wres<128,512>", 0) >= 2, counts
+        assert counts.get("k_gemm5+rope", 0) == 2 and counts.get("k_mimi_ffn", 0) == 2, counts
     for u in (0, 9, 15):
         pkg.runtime.launch_counts(True)
         _, _, one = gm.decode_stages(np.ascontiguousarray(x[u:u + 1, :48]))
