@@ -281,6 +281,21 @@ def roofline_pass(pkg, model, wl, prompts, voice, traffic=None):
          "achieved_with_activations": round(with_act, 1), "frac_with_activations": round(with_act / HBM_PEAK_GBS, 4),
          "bytes_per_launch_with_activations": round(prof["algorithmic_bytes"] / n),
          "phases_ms": {"prefill": round(prof["prefill_ms"], 3), "ar_loop": round(prof["ar_loop_ms"], 3), "mimi": round(prof["mimi_ms"], 3)}}
+    # the same kernel's mean as rocprofv3 reports it for the same workload under graph replay (a child pass of this run).  Under the profiler every
+    # launch is a little longer and the chip's clock a little lower (2-3 %), the in-process events see the kernels launched one by one; where the two
+    # differ, `frac` is priced with the LONGER one, and both stand in the line.
+    tr = (traffic or {}).pop("_trace", None) if isinstance(traffic, dict) else None
+    if tr and tr[0]:
+        r["avg_launch_us_rocprof"] = round(tr[0], 3)
+        r["launches_rocprof"] = tr[1]
+        slow = max(tr[0], r["avg_launch_us"])
+        r["avg_launch_us_events"] = r["avg_launch_us"]
+        r["achieved_events"] = r["achieved"]
+        r["achieved"] = round(r["algorithmic_bytes_per_launch"] / (slow * 1e-6) / 1e9, 1)
+        r["frac"] = round(r["achieved"] / HBM_PEAK_GBS, 4)
+        r["frac_note"] = "achieved / frac use the longer of the two mean launch durations (in-process events, rocprofv3 kernel trace of the same workload)"
+    elif tr:
+        r["avg_launch_us_rocprof_note"] = tr[2]
     if traffic and traffic.get(prof["kernel"]):
         t = traffic[prof["kernel"]]
         r["traffic"] = t.get("bytes_per_launch")
@@ -327,6 +342,34 @@ def _pmc_pass(counters, out_dir, steps):
         v[0] += float(r["Counter_Value"])
         v[1] += 1
     return per, None
+
+
+def trace_pass(steps, kernel="k_skinny"):
+    """rocprofv3 --kernel-trace over the headline workload (tools/traffic_probe.py with graph replay and `steps` frames per utterance, a child
+    process): the launch-weighted mean duration of the dominant kernel as the profiler itself reports it -- the figure profiles/r4_by_grid.txt
+    holds -- to stand in the bench line beside the in-process (hipExtLaunchKernel event) figure.  Returns (mean_us, launches, note)."""
+    exe = shutil.which("rocprofv3") or next((p for p in ("/opt/rocm/bin/rocprofv3",) if os.path.exists(p)), None)
+    if not exe:
+        return None, 0, "rocprofv3 not found"
+    out_dir = tempfile.mkdtemp(prefix="ptts_trace_")
+    try:
+        env = dict(os.environ, PTTS_PROBE_STEPS=str(steps), PTTS_PROBE_GRAPH="1", PTTS_PROBE_REPS="2", TMPDIR=tempfile.gettempdir())
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "tr", "--", sys.executable, os.path.join(ROOT, "tools", "traffic_probe.py")]
+        try:
+            p = subprocess.run(cmd, env=env, cwd=tempfile.gettempdir(), capture_output=True, text=True, timeout=420)
+        except subprocess.TimeoutExpired:
+            return None, 0, "rocprofv3 kernel-trace pass timed out"
+        files = glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True)
+        if p.returncode != 0 or not files:
+            return None, 0, f"rocprofv3 --kernel-trace failed (rc {p.returncode}): {(p.stderr or '')[-300:]}"
+        tot, n = 0, 0
+        for r in csv.DictReader(open(files[0])):
+            if kernel in r["Kernel_Name"]:
+                tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                n += 1
+        return (tot / n / 1e3 if n else None), n, None
+    finally:
+        shutil.rmtree(out_dir, ignore_errors=True)
 
 
 def measure_traffic(steps=12):
@@ -492,6 +535,7 @@ def main():
         t0 = time.time()
         try:
             traffic = measure_traffic()
+            traffic["_trace"] = trace_pass(WORKLOADS[args.workload]["frames"]) if args.workload == "b64_10s_bf16" else (None, 0, "only for the headline workload")
         except Exception as e:  # noqa: BLE001
             traffic = {"_notes": [f"traffic measurement failed: {e}"]}
         log(f"[bench] PMC traffic passes took {time.time()-t0:.1f}s: { {k: v for k, v in traffic.items() if k == 'k_skinny' or k.startswith('_n')} }")

@@ -1030,6 +1030,33 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
     });
 }
 
+int ptts_mimi_layer_piece(ptts_model* h, int32_t layer, int32_t which, const float* x, int64_t rows, int32_t pos0, int32_t rows_per_seg, float* out) {
+    return guard([&] {
+        if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
+        Model& m = *h->m;
+        const Desc& d = m.d;
+        if (!x || !out || rows <= 0 || rows > (1 << 24)) throw Error(PTTS_EINVAL, "ptts-hip: bad rows");
+        if (layer < 0 || layer >= d.mimi_layers) throw Error(PTTS_EINVAL, strfmt("ptts-hip: mimi layer %d out of range [0,%d)", layer, d.mimi_layers));
+        if (which != PTTS_MIMI_PIECE_QKV && which != PTTS_MIMI_PIECE_FFN) throw Error(PTTS_EINVAL, "ptts-hip: unknown layer piece");
+        if (pos0 < 0 || rows_per_seg < 0 || (int64_t)pos0 + (rows_per_seg ? rows_per_seg : rows) > ROPE_SEQ)
+            throw Error(PTTS_EINVAL, strfmt("ops: rope cos/sin sequence length too small for pos=%d seq=%lld", pos0, (long long)(rows_per_seg ? rows_per_seg : rows)));
+        std::lock_guard<std::mutex> lock(m.mu);
+        m.use_device();
+        const int C = d.mimi_dim, F = d.mimi_ffn, R = (int)rows;
+        const int NO = which == PTTS_MIMI_PIECE_QKV ? 3 * C : C;
+        Tmp dx((size_t)R * C * 4), dn((size_t)R * C * 4), dy((size_t)R * std::max(NO, F) * 4);
+        PTTS_HIP(hipMemcpyAsync(dx.p, x, (size_t)R * C * 4, hipMemcpyHostToDevice, m.stream));
+        if (which == PTTS_MIMI_PIECE_QKV) {
+            mimi_layer_qkv(m, layer, dx.as<float>(), RowMap{C, 0, 0}, R, dy.as<float>(), RowMap{3 * C, 0, 0}, pos0, rows_per_seg, dn.as<float>(), m.stream);
+            PTTS_HIP(hipMemcpyAsync(out, dy.p, (size_t)R * NO * 4, hipMemcpyDeviceToHost, m.stream));
+        } else {
+            mimi_layer_ffn(m, layer, dx.as<float>(), RowMap{C, 0, 0}, R, dn.as<float>(), dy.as<float>(), m.stream);
+            PTTS_HIP(hipMemcpyAsync(out, dx.p, (size_t)R * NO * 4, hipMemcpyDeviceToHost, m.stream));
+        }
+        PTTS_HIP(hipStreamSynchronize(m.stream));
+    });
+}
+
 int ptts_op_linear(const float* x, const float* w, const float* bias, int64_t rows, int64_t in, int64_t out, float* y) {
     return guard([&] {
         require_device();

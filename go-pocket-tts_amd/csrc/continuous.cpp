@@ -27,6 +27,7 @@
 namespace ptts {
 
 namespace {
+int tune(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }   // (tuning sweep: tools/gpu_serve_sweep.sh)
 constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
 }
 
@@ -470,7 +471,8 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
         if (!e.staged.empty()) {
             uint64_t oldest = e.seq;
             for (const ContEngine::Staged& f : e.staged) oldest = std::min(oldest, f.seq);
-            if ((int)e.staged.size() >= std::max(4, B / 3) || e.seq - oldest >= 8 || e.n_gen == 0 || drain) start_decode(e, e.staged);
+            static const int dmin = tune("PTTS_CONT_DECODE_MIN", 0), dage = tune("PTTS_CONT_DECODE_AGE", 8);
+            if ((int)e.staged.size() >= (dmin > 0 ? dmin : std::max(4, B / 3)) || (int)(e.seq - oldest) >= dage || e.n_gen == 0 || drain) start_decode(e, e.staged);
         }
         while (!e.decoding.empty()) {
             ContEngine::Pending& p = e.decoding.front();
@@ -494,8 +496,9 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
 bool cont_admit_now(const ContEngine& e, int waiting) {
     if (waiting <= 0 || e.free_slots() == 0) return false;
     if (e.n_gen == 0) return true;
-    if (e.seq - e.last_admit_seq >= 4) return true;
-    return std::min(waiting, e.free_slots()) >= std::max(1, e.B / 4);
+    static const int every = tune("PTTS_CONT_ADMIT_EVERY", 4), quarter = tune("PTTS_CONT_ADMIT_MIN", 0);
+    if ((int)(e.seq - e.last_admit_seq) >= every) return true;
+    return std::min(waiting, e.free_slots()) >= (quarter > 0 ? quarter : std::max(1, e.B / 4));
 }
 
 // every request in flight is answered with `code` (the engine is about to be torn down after an error)

@@ -251,6 +251,18 @@ struct FfnArgs {
     const float* ls = nullptr;      // [D] layer scale or null (1)
     int M = 0, D = 0, F = 0;
 };
+// LayerNorm + linear (+ RoPE on the first rope_cols output columns, head width 64) with register-resident rows (ffn_fused.hip k_mimi_rowlin):
+// y[M][N] = rope(LayerNorm(x)[M][512] * W[N][512]^T); img: W as W1-format chunk images (model.cpp add_w1_image, bf16); no bias
+struct RowLinArgs {
+    const float* x = nullptr; RowMap xmap;
+    const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+    const void* img = nullptr;
+    float* y = nullptr; RowMap ymap;
+    const float* rope_cos = nullptr; const float* rope_sin = nullptr; int rope_cols = 0, rope_pos0 = 0, rope_rows_per_seg = 0;   // tables [pos][32]
+    int M = 0, N = 0, K = 0;
+};
+bool mimi_rowlin_supported(const RowLinArgs& a);
+void launch_mimi_rowlin(const RowLinArgs& a, hipStream_t stream);
 bool mimi_ffn_supported(const FfnArgs& a);
 void launch_mimi_ffn(const FfnArgs& a, hipStream_t stream);
 

@@ -184,6 +184,30 @@ struct Walker {
     //     W2[o][32c + 16 + 4q + (0..3)].
     // The positions make every ds_read_b128 fragment read conflict-free (16 lanes of a service group on 16 different 16-byte bank slots); the k order
     // inside a piece is the order in which a pair of 16x16 accumulator tiles hands its values to the next product.
+    // rows [32c, 32c + 32) of a row-major [N][512] matrix as one 32-KB W1-format image (above)
+    static void w1_image_chunk(const std::vector<float>& w, int c, uint16_t* i1) {
+        const int D = 512;
+        for (int j = 0; j < 8; j++)
+            for (int h = 0; h < 32; h++)
+                for (int sg = 0; sg < 2; sg++)
+                    for (int q = 0; q < 4; q++) {
+                        const int pos = (4 * sg + q) ^ ((h >> 1) & 7), s = 2 * j + sg;
+                        uint16_t* p = i1 + ((size_t)j * 32 + h) * 64 + pos * 8;
+                        for (int e = 0; e < 8; e++) {
+                            const int k = 32 * s + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
+                            p[e] = f32_to_bf16_rne(w[(size_t)(32 * c + h) * D + k]);
+                        }
+                    }
+    }
+    // a [N][512] matrix as N / 32 consecutive W1-format images (k_mimi_rowlin)
+    size_t add_w1_image(const std::string& wn, int N) {
+        const int nch = N / 32;
+        const size_t off = reserve((size_t)nch * 32768);
+        if (!host) return off;
+        const std::vector<float> w = load(wn);
+        for (int c = 0; c < nch; c++) w1_image_chunk(w, c, reinterpret_cast<uint16_t*>(host + off) + (size_t)c * 16384);
+        return off;
+    }
     size_t add_ffn_image(const std::string& w1n, const std::string& w2n, int F) {
         const int D = 512, nch = F / 32;
         const size_t off = reserve((size_t)nch * 65536);
@@ -193,17 +217,7 @@ struct Walker {
         for (int c = 0; c < nch; c++) {
             uint16_t* i1 = dst + (size_t)c * 32768;          // (uint16 units: 64 KB per chunk)
             uint16_t* i2 = i1 + 16384;
-            for (int j = 0; j < 8; j++)
-                for (int h = 0; h < 32; h++)
-                    for (int sg = 0; sg < 2; sg++)
-                        for (int q = 0; q < 4; q++) {
-                            const int pos = (4 * sg + q) ^ ((h >> 1) & 7), s = 2 * j + sg;
-                            uint16_t* p = i1 + ((size_t)j * 32 + h) * 64 + pos * 8;
-                            for (int e = 0; e < 8; e++) {
-                                const int k = 32 * s + (e < 4 ? 4 * q + e : 16 + 4 * q + (e - 4));
-                                p[e] = f32_to_bf16_rne(w1[(size_t)(32 * c + h) * D + k]);
-                            }
-                        }
+            w1_image_chunk(w1, c, i1);
             for (int o = 0; o < D; o++)
                 for (int q = 0; q < 4; q++) {
                     const int pos = q ^ (3 * ((o >> 3) & 1));
@@ -538,6 +552,8 @@ struct Walker {
             if (L.out_proj.out % d.mimi_heads) throw Error(PTTS_EFORMAT, strfmt("native: mimi d_model %d not divisible by heads %d", L.out_proj.out, d.mimi_heads));
             if (bf16w && L.l1.in == 512 && L.l2.out == 512 && L.l1.out == L.l2.in && L.l1.out % 32 == 0 && L.l1.b == NONE && L.l2.b == NONE)
                 L.ffn_img = add_ffn_image(p + ".linear1.weight", p + ".linear2.weight", L.l1.out);
+            if (bf16w && L.in_proj.in == 512 && L.in_proj.out % 64 == 0 && L.in_proj.b == NONE)
+                L.qkv_img = add_w1_image(p + ".self_attn.in_proj.weight", L.in_proj.out);
             d.mimi_layers++;
         }
         if (d.mimi_layers == 0) throw Error(PTTS_EFORMAT, "native: no mimi decoder transformer layers found");

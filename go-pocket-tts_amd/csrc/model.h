@@ -53,6 +53,7 @@ struct Desc {
     struct ML {
         Norm n1, n2; Lin in_proj, out_proj, l1, l2; size_t ls1 = NONE, ls2 = NONE;
         size_t ffn_img = NONE;   // linear1 / linear2 as the per-chunk LDS images of the fused feed-forward kernel (ffn_fused.hip; bf16 weights, width 512)
+        size_t qkv_img = NONE;   // in_proj as W1-format chunk images for k_mimi_rowlin (norm1 + in_proj + RoPE in one launch)
     } ml[MAX_LAYERS];
     int sea_ch[4] = {0, 0, 0, 0};        // channels after initConv, up1, up2, up3
     int sea_hidden[3] = {0, 0, 0};

@@ -807,6 +807,60 @@ void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s) {
     w.zeroed = true;
 }
 
+// Two pieces of a decoder-transformer layer (mimi.go:245-441) as the decoder launches them; also reachable on their own through
+// ptts_mimi_layer_piece (staged parity checks).
+// norm1 -> in_proj (no bias) -> RoPE of q and k at positions pos0 + (row % rows_per_seg): x rows [R][C] -> qkv rows [R][3C].  n1: [R][C] scratch.
+void mimi_layer_qkv(Model& m, int l, const float* x, RowMap xmap, int R, float* qkv, RowMap qmap, int pos0, int rows_per_seg, float* n1, hipStream_t s) {
+    const Desc& d = m.d;
+    const auto& L = d.ml[l];
+    const int C = d.mimi_dim;
+    if (L.qkv_img != NONE && d.mimi_hd == 64) {   // one kernel (ffn_fused.hip k_mimi_rowlin)
+        RowLinArgs ra;
+        ra.x = x; ra.xmap = xmap;
+        ra.ln_w = m.at<float>(L.n1.w); ra.ln_b = m.at<float>(L.n1.b); ra.eps = L.n1.eps;
+        ra.img = m.at<uint8_t>(L.qkv_img);
+        ra.y = qkv; ra.ymap = qmap;
+        ra.rope_cos = m.at<float>(d.rope_cos); ra.rope_sin = m.at<float>(d.rope_sin); ra.rope_cols = 2 * C; ra.rope_pos0 = pos0; ra.rope_rows_per_seg = rows_per_seg;
+        ra.M = R; ra.N = 3 * C; ra.K = C;
+        static const int want = [] { const char* e = getenv("PTTS_QKV_FUSED"); return e ? atoi(e) : 1; }();   // A/B measurement
+        if (want && mimi_rowlin_supported(ra)) { launch_mimi_rowlin(ra, s); return; }
+    }
+    launch_layernorm(mkln(m, x, xmap, L.n1, n1, C, R), s);
+    GemmArgs gq = mk(m, n1, flat(C), L.in_proj, qkv, qmap, R);
+    gq.rope_cos = m.at<float>(d.rope_cos); gq.rope_sin = m.at<float>(d.rope_sin);   // q and k are rotated in the epilogue
+    gq.rope_cols = 2 * C; gq.rope_hd = d.mimi_hd; gq.rope_pos0 = pos0; gq.rope_rows_per_seg = rows_per_seg;
+    if (!launch_gemm_rope(gq, s)) {
+        gq.rope_cos = gq.rope_sin = nullptr;
+        launch_gemm(gq, s);
+        launch_rope_rows(qkv, qmap, 0, d.mimi_heads, d.mimi_hd, nullptr, pos0, rows_per_seg, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+        launch_rope_rows(qkv, qmap, C, d.mimi_heads, d.mimi_hd, nullptr, pos0, rows_per_seg, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
+    }
+}
+
+// x += layer_scale_2 * linear2(gelu(linear1(norm2(x)))) on rows [R][C], in place.  n1: [R][C], ffb: [R][F] scratch (unused by the fused kernel).
+void mimi_layer_ffn(Model& m, int l, float* x, RowMap xmap, int R, float* n1, float* ffb, hipStream_t s) {
+    const Desc& d = m.d;
+    const auto& L = d.ml[l];
+    const int C = d.mimi_dim, F = d.mimi_ffn;
+    if (L.ffn_img != NONE) {   // one kernel (ffn_fused.hip k_mimi_ffn)
+        FfnArgs fa;
+        fa.x = x; fa.xmap = xmap;
+        fa.ln_w = m.at<float>(L.n2.w); fa.ln_b = m.at<float>(L.n2.b); fa.eps = L.n2.eps;
+        fa.img = m.at<uint8_t>(L.ffn_img);
+        fa.ls = m.at<float>(L.ls2);
+        fa.M = R; fa.D = C; fa.F = F;
+        static const int want = [] { const char* e = getenv("PTTS_FFN_FUSED"); return e ? atoi(e) : 1; }();   // A/B measurement
+        if (want && mimi_ffn_supported(fa)) { launch_mimi_ffn(fa, s); return; }
+    }
+    launch_layernorm(mkln(m, x, xmap, L.n2, n1, C, R), s);
+    GemmArgs g1 = mk(m, n1, flat(C), L.l1, ffb, flat(F), R);
+    g1.epi = EPI_GELU;
+    launch_gemm(g1, s);
+    GemmArgs g2 = mk(m, ffb, flat(F), L.l2, x, xmap, R);
+    g2.R = x; g2.epi = L.ls2 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; g2.scale = m.at<float>(L.ls2);
+    launch_gemm(g2, s);
+}
+
 // frames [f0, f1) of every utterance; lat: device [B][*][ldim] with lat_bstride elements between utterances;
 // pcm: device [B][T * samples_per_frame]; mimi_latent (optional): [B][C][T] (whole range only)
 void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
@@ -824,6 +878,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
     launch_upsample_depthwise(w.xp, m.at<float>(d.up_w0), m.at<float>(d.up_w1), nullptr, B, T, f0, f1, C, S, w.up, P0, s);
     // decoder transformer (mimi.go:245-441, 506-525): positions restart at 0 for every utterance, window `context`
     const int t0 = f0 * S, CT = nf * S, R = B * CT;
+    (void)F;
     const int64_t up_bs = (int64_t)(P0 + T1) * C;
     float* upx = w.up + (size_t)(P0 + t0) * C;            // chunk rows of the residual stream
     const RowMap upm = seg(C, CT, up_bs);
@@ -835,18 +890,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         float* qkv = w.qkv[l];                              // [B][T1][3C], persists across ranges (keys/values of earlier frames)
         float* qkvx = qkv + (size_t)t0 * 3 * C;
         const RowMap qm = seg(3 * C, CT, (int64_t)T1 * 3 * C);
-        launch_layernorm(mkln(m, upx, upm, L.n1, n1, C, R), s);
-        {
-            GemmArgs gq = mk(m, n1, flat(C), L.in_proj, qkvx, qm, R);
-            gq.rope_cos = m.at<float>(d.rope_cos); gq.rope_sin = m.at<float>(d.rope_sin);   // q and k are rotated in the epilogue
-            gq.rope_cols = 2 * C; gq.rope_hd = d.mimi_hd; gq.rope_pos0 = t0; gq.rope_rows_per_seg = CT;
-            if (!launch_gemm_rope(gq, s)) {
-                gq.rope_cos = gq.rope_sin = nullptr;
-                launch_gemm(gq, s);
-                launch_rope_rows(qkvx, qm, 0, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
-                launch_rope_rows(qkvx, qm, C, d.mimi_heads, d.mimi_hd, nullptr, t0, CT, R, m.at<float>(d.rope_cos), m.at<float>(d.rope_sin), s);
-            }
-        }
+        mimi_layer_qkv(m, l, upx, upm, R, qkvx, qm, t0, CT, n1, s);
         AttnArgs a;
         a.q = qkvx; a.q_ld = 3 * C; a.q_col0 = 0; a.q_rows_per_batch = CT; a.q_batch_stride = (int64_t)T1 * 3 * C;
         a.k = qkv + C; a.v = qkv + 2 * C; a.kv_bf16 = 0;
@@ -859,23 +903,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs go = mk(m, attn, flat(C), L.out_proj, upx, upm, R);
         go.R = upx; go.epi = L.ls1 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; go.scale = m.at<float>(L.ls1);
         launch_gemm(go, s);
-        if (L.ffn_img != NONE) {   // norm2 + linear1 + GELU + linear2 + layer scale + residual as one kernel (ffn_fused.hip)
-            FfnArgs fa;
-            fa.x = upx; fa.xmap = upm;
-            fa.ln_w = m.at<float>(L.n2.w); fa.ln_b = m.at<float>(L.n2.b); fa.eps = L.n2.eps;
-            fa.img = m.at<uint8_t>(L.ffn_img);
-            fa.ls = m.at<float>(L.ls2);
-            fa.M = R; fa.D = C; fa.F = F;
-            static const int want = [] { const char* e = getenv("PTTS_FFN_FUSED"); return e ? atoi(e) : 1; }();   // A/B measurement
-            if (want && mimi_ffn_supported(fa)) { launch_mimi_ffn(fa, s); continue; }
-        }
-        launch_layernorm(mkln(m, upx, upm, L.n2, n1, C, R), s);
-        GemmArgs g1 = mk(m, n1, flat(C), L.l1, ffb, flat(F), R);
-        g1.epi = EPI_GELU;
-        launch_gemm(g1, s);
-        GemmArgs g2 = mk(m, ffb, flat(F), L.l2, upx, upm, R);
-        g2.R = upx; g2.epi = L.ls2 != NONE ? EPI_SCALE_RESADD : EPI_RESADD; g2.scale = m.at<float>(L.ls2);
-        launch_gemm(g2, s);
+        mimi_layer_ffn(m, l, upx, upm, R, n1, ffb, s);
     }
     if (xformer_out)   // staged parity check: the residual stream after the last layer, [B][T1][C] (rows of this range)
         PTTS_HIP(hipMemcpy2DAsync(xformer_out + (size_t)t0 * C, (size_t)T1 * C * sizeof(float), upx, (size_t)up_bs * sizeof(float), (size_t)CT * C * sizeof(float),

@@ -174,6 +174,8 @@ void mimi_setup(Model& m, MimiWs& w, int B, int T);
 void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int f0, int f1, float* pcm, float* mimi_latent, hipStream_t s,
                 const PcmRow* pcm_rows = nullptr, bool* rows_used = nullptr, float* xformer_out = nullptr);
 
+void mimi_layer_qkv(Model& m, int layer, const float* x, RowMap xmap, int R, float* qkv, RowMap qmap, int pos0, int rows_per_seg, float* n1, hipStream_t s);
+void mimi_layer_ffn(Model& m, int layer, float* x, RowMap xmap, int R, float* n1, float* ffb, hipStream_t s);
 Model* model_open(Plan* plan, void* device_arena, int fill);
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps);
 void batch_reset(Batch& b);

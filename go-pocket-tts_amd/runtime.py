@@ -104,6 +104,7 @@ ABI_SYMBOLS = [
     "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast", "ptts_dsp_apply",
     "ptts_voice_file_open", "ptts_voice_file_open_bytes", "ptts_voice_file_close", "ptts_voice_file_kind", "ptts_voice_file_embedding",
     "ptts_voice_file_modules", "ptts_voice_file_module", "ptts_voice_file_state", "ptts_voice_open", "ptts_voice_open_bytes",
+    "ptts_mimi_layer_piece",
 ]
 
 
@@ -176,6 +177,7 @@ def lib():
         L.ptts_voice_file_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_FP), _IP, _IP]
         L.ptts_voice_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.ptts_voice_open_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.ptts_mimi_layer_piece.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int32, _FP]
         L.ptts_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.ptts_profile_read.argtypes = [C.c_void_p, C.POINTER(_Profile)]
         L.ptts_op_linear.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int64, C.c_int64, _FP]
@@ -380,6 +382,20 @@ class Model:
         h = C.c_void_p()
         _check(lib().ptts_voice_create(self.h, ptrs, _ip(steps), _ip(offs), C.byref(h)))
         return DeviceVoice(h.value, int(offs[0]))
+
+    def mimi_layer_qkv(self, layer: int, x, pos0: int = 0, rows_per_seg: int = 0) -> np.ndarray:
+        """norm1 -> in_proj -> RoPE(q, k) of Mimi decoder-transformer layer `layer` on rows x [R, 512] -> [R, 1536] (ptts_mimi_layer_piece)."""
+        x = _f32(x)
+        out = np.empty((x.shape[0], 3 * x.shape[1]), np.float32)
+        _check(lib().ptts_mimi_layer_piece(self.h, layer, 0, _fp(x), x.shape[0], pos0, rows_per_seg, _fp(out)))
+        return out
+
+    def mimi_layer_ffn(self, layer: int, x) -> np.ndarray:
+        """x + layer_scale_2 * linear2(gelu(linear1(norm2(x)))) of Mimi decoder-transformer layer `layer` on rows x [R, 512]."""
+        x = _f32(x)
+        out = np.empty_like(x)
+        _check(lib().ptts_mimi_layer_piece(self.h, layer, 1, _fp(x), x.shape[0], 0, 0, _fp(out)))
+        return out
 
     def open_voice(self, src) -> "DeviceVoice":
         """A model-state voice file (path, or the file's bytes) straight into HBM: safetensors.LoadVoiceModelState +

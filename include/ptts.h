@@ -329,6 +329,13 @@ int  ptts_batch_step(ptts_batch* b, const float* frames_in, int32_t lsd_steps, c
                      float* frames_out, float* eos_logits, float* last_hidden);
 int  ptts_batch_offsets(ptts_batch* b, int64_t* out /* [n_slots] */);
 int  ptts_batch_read_kv(ptts_batch* b, int32_t slot, int32_t layer, float* k, float* v /* [H, offset, Dh] each */);
+/* Pieces of one Mimi decoder-transformer layer on host rows, through the kernels the decoder itself launches for them (staged parity checks of
+ * mimiTransformerLayer, mimi.go:245-441).  which = PTTS_MIMI_PIECE_QKV: norm1 -> in_proj -> RoPE of q and k at positions pos0 + (row % rows_per_seg)
+ * (rows_per_seg 0: pos0 + row): x [rows, mimi_dim] -> out [rows, 3 mimi_dim] (q | k | v).  which = PTTS_MIMI_PIECE_FFN: x + layer_scale_2 *
+ * linear2(gelu(linear1(norm2(x)))): x [rows, mimi_dim] -> out [rows, mimi_dim]. */
+#define PTTS_MIMI_PIECE_QKV 0
+#define PTTS_MIMI_PIECE_FFN 1
+int  ptts_mimi_layer_piece(ptts_model* m, int32_t layer, int32_t which, const float* x, int64_t rows, int32_t pos0, int32_t rows_per_seg, float* out);
 /* Model.LatentToMimi + Model.MimiDecode: latents [n_utt, frames, ldim] host -> pcm [n_utt, frames*samples_per_frame] host;
  * mimi_latent (optional) receives LatentToMimi's [n_utt, mimi_dim, frames] */
 int  ptts_decode_latents(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,

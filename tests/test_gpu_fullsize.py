@@ -38,11 +38,26 @@ TF_BF16_FRAME, TF_BF16_LOGIT = 2.7e-3, 1.8e-3    # observed 2.7e-4 / 1.8e-4; bf1
 # free-running head of an utterance (3 / 6 frames)
 HEAD_F32_LAT, HEAD_F32_PCM = (2.5e-4, 6e-3), (2.4e-4, None)     # observed 2.5e-5 / 6.3e-4, 2.4e-5
 HEAD_BF16_LAT, HEAD_BF16_PCM = (1.4e-2, None), (1e-2, None)     # observed 1.4e-3, 1.1e-3
-# free-running, whole length: GPU-vs-oracle error at step t over the running maximum of the reference's own AVX2-vs-scalar
-# difference up to t (both amplified by the model's dynamics at the same rate; the GPU's bf16 hi/lo operand split starts ~13x
-# above a pure summation-order change)
-ENVELOPE_FACTOR = 70.0    # observed 26.7 with round 2's kernels, 34.8 with round 3's (a one-ulp change of summation order moves it: the ratio of two
-                          # chaotic error curves); 2x the larger.  Deterministic per build: the same kernels give the same ratio on every box
+# free-running, whole length.  A random-init model amplifies ANY perturbation of a frame by a fixed rate per step (the reference's own AVX2 and scalar
+# builds drift apart at that rate), so the free-running error curve is held to the two quantities that are properties of the kernels rather than of
+# a chaotic trajectory: where it STARTS (frame 0: the kernels' own error, <= 10x observed) and how fast it GROWS (the fitted per-step factor must be
+# the model's own -- the one the reference's two summation orders show -- within FREE_RATE_SLACK: a kernel that injects error at every step would
+# start low and grow faster).  Round 3 bounded the ratio of the two curves by a factor 70 around an observed 27-35: a ratio of two chaotic
+# curves, which one ulp of summation order moved by 30 %; it is still recorded, no longer asserted.
+FREE_F32_FRAME0 = 3.4e-4      # observed 3.4e-5 of scale (bf16 hi/lo operand split: ~13x a pure summation-order change, 2.6e-6)
+FREE_RATE_SLACK = 1.05        # observed: GPU 1.158 per step, reference AVX2-vs-scalar 1.150 (ratio 1.007)
+
+
+def growth_rate(curve, scale):
+    """Per-step factor of an error curve: least-squares slope of log(error) over the steps before it saturates (error < 5 % of scale)."""
+    c = np.asarray(curve, np.float64)
+    n = int(np.argmax(c >= 0.05 * scale)) if (c >= 0.05 * scale).any() else len(c)
+    n = max(n, 8)
+    t = np.arange(n)
+    ok = c[:n] > 0
+    slope = np.polyfit(t[ok], np.log(c[:n][ok]), 1)[0]
+    return float(np.exp(slope))
+
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -197,9 +212,14 @@ def test_config1_full_length_63_frames_f32(pkg, full):
     lat, _ = error_curve("config1_f32_63", got, ref)
     own = np.abs(ref["latents"].astype(np.float64) - ref_scalar["latents"]).max(axis=1)
     ratio = float((lat / np.maximum.accumulate(own)).max())
-    print(f"[free] reference AVX2 vs scalar order: {own[0]:.2e} -> {own[-1]:.2e}; GPU vs oracle: {lat[0]:.2e} -> {lat[-1]:.2e}; max ratio {ratio:.1f}")
-    record("config1 free-running: GPU error / reference's own AVX2-vs-scalar envelope (63 frames)", ratio, 0.0, 1.0, (ENVELOPE_FACTOR, 0))
-    assert ratio <= ENVELOPE_FACTOR, ratio
+    r_gpu, r_ref = growth_rate(lat, scale), growth_rate(own, scale)
+    print(f"[free] reference AVX2 vs scalar order: {own[0]:.2e} -> {own[-1]:.2e} (x{r_ref:.3f} per step); GPU vs oracle: {lat[0]:.2e} -> {lat[-1]:.2e} "
+          f"(x{r_gpu:.3f} per step); max ratio of the curves {ratio:.1f}")
+    record("config1 free-running: frame-0 error (63 frames, f32)", float(lat[0]), 0.0, scale, (FREE_F32_FRAME0, 0))
+    record("config1 free-running: per-step growth of the GPU error / of the reference's own AVX2-vs-scalar difference", r_gpu / r_ref, 0.0, 1.0, (FREE_RATE_SLACK, 0))
+    record("config1 free-running: GPU error / reference's own AVX2-vs-scalar envelope (63 frames; recorded, not asserted)", ratio, 0.0, 1.0, (0, 0))
+    assert lat[0] <= FREE_F32_FRAME0 * max(1.0, scale), (float(lat[0]), scale)
+    assert r_gpu <= FREE_RATE_SLACK * r_ref, (r_gpu, r_ref)
     gm.set_use_graph(True)
     again = pkg.Runtime(gm).generate(toks, c)
     assert np.array_equal(again.latents, got.latents) and np.array_equal(again.pcm, got.pcm)
@@ -291,8 +311,8 @@ def test_last_stage_as_one_kernel_gives_the_two_launch_samples_bit_for_bit(pkg, 
         assert c1.get("k_resblock+final", 0) == 1 and c1.get("k_resblock_up+final", 0) == 0, c1
         assert np.array_equal(both[u], one[0]), (u, float(np.abs(both[u] - one[0]).max()))
     om = O.OracleModel.from_file(paths["BF16"])
-    want = om.mimi_decode(om.latent_to_mimi(x[0][:6]))           # the decoder is causal: 6 frames of the oracle = the first 6 of 100
-    parity("fused last stage pcm (6 frames, bf16 weights)", both[0][: want.shape[-1]], want.reshape(-1), 2e-4, 5e-2)
+    want = om.mimi_decode(om.latent_to_mimi(x[0]))               # ALL 100 frames of one utterance against the oracle's decoder (192 000 samples)
+    parity("fused last stage pcm (100 frames, bf16 weights)", both[0], want.reshape(-1), 2e-4, 5e-2)
     om.close()
     gm.close()
 
@@ -328,5 +348,17 @@ def test_last_stage_kernel_decodes_frame_ranges_behind_the_ar_loop(pkg, full):
         assert offs[0] == 0 and all(offs[k + 1] == offs[k] + sizes[k] for k in range(len(offs) - 1)) and offs[-1] + sizes[-1] == frames * 1920
         assert np.array_equal(np.concatenate([c for _, c in chunks[i]]), got[i].pcm)
         assert np.abs(got[i].pcm.astype(np.int32) - whole[i].pcm.astype(np.int32)).max() <= 2, i
+    # ... and the RANGE-mode audio against the oracle itself: two utterances' streamed samples (all 48 frames) vs the oracle's decoder run on the
+    # very latents the GPU produced, through the reference's own int16 conversion (wav_stream.go:43-54): +/-2 LSB of rounding room on top of the
+    # decoder's float tolerance
+    om = O.OracleModel.from_file(paths["BF16"])
+    for i in (0, 11):
+        want = om.mimi_decode(om.latent_to_mimi(got[i].latents)).reshape(-1)
+        scale = float(np.abs(want).max())
+        want16 = (np.clip(want.astype(np.float64), -1.0, 1.0) * 32767.0).astype(np.int64)   # int16(clamp(s) * 32767): truncation toward zero
+        err = np.abs(got[i].pcm.astype(np.int64) - want16).max()
+        record(f"range-mode pcm16 vs oracle [{i}]", float(err), 0.0, 32767.0 * scale, (2 + 2e-4 * 32767.0 * max(scale, 1.0), None))
+        assert err <= 2 + 2e-4 * 32767.0 * max(scale, 1.0), (i, int(err), scale)
+    om.close()
     dv.close()
     gm.close()

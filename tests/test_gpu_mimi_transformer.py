@@ -4,8 +4,10 @@ on checkpoints whose layer_scale is ~1, so that the attention / MLP branches car
 
 What is under test, by kernel (asserted through the launch census, so a silent re-route cannot pass):
   k_attn_window          the 250-key sliding window (mimi.go:32,418; attention.go:473-484)
-  k_gemm3+rope / k_gemm5+rope   qkv projection with the interleaved-pair RoPE epilogue (rope.go:81-105); k_gemm5: bf16 weights, >= 1024 rows
-  k_gemm3 / k_gemm5 / k_gemm_wres<128,512>   out_proj (+ layer_scale_1, residual), linear1 + GELU, linear2 (+ layer_scale_2, residual)
+  k_mimi_rowlin+rope     bf16 weights: norm1 + qkv projection + interleaved-pair RoPE (rope.go:81-105) as one row-resident kernel (ffn_fused.hip)
+  k_gemm3+rope           f32 weights: the qkv projection with the RoPE epilogue behind a LayerNorm launch
+  k_mimi_ffn             bf16 weights: norm2 + linear1 + GELU + linear2 + layer_scale_2 + residual as one kernel; f32 weights: k_gemm3 per linear
+  k_gemm3 / k_gemm5      out_proj (+ layer_scale_1, residual)
 Tolerance: abs 1e-4 of max|want| (half the reference's flow-level budget of 2e-4, native/python_parity_test.go:86; observed on
 MI355X: 1.1e-5) and rel 5e-3 on the elements >= 1 % of max|want| (with the floor at 0.1 % the relative figure is 5-6e-3 and
 is nothing but the same 6e-5 absolute error divided by 6e-3-sized elements).  BF16 files are compared with the oracle run on
@@ -36,6 +38,7 @@ def mimi_full(request, pkg, tmp_path_factory):
     synth.write_safetensors(path, synth.make_checkpoint(cfg, seed=4242), dtype=request.param)
     om = O.OracleModel.from_file(path)
     gm = pkg.Model.open(path, device=0, weights=1 if request.param == "BF16" else 0)
+    gm.path = path
     yield request.param, om, gm
     gm.close()
     om.close()
@@ -57,7 +60,7 @@ def test_transformer_output_against_the_oracle(pkg, mimi_full, frames):
     counts = pkg.runtime.launch_counts(False)
     assert counts.get("k_attn_window", 0) == 2 and "k_attention" not in counts, counts
     if 2 * 16 * frames >= 512:
-        rope = "k_gemm5+rope" if dtype == "BF16" and 2 * 16 * frames >= 1024 else "k_gemm3+rope"   # k_gemm5: bf16 weights from 1024 rows
+        rope = "k_mimi_rowlin+rope" if dtype == "BF16" else "k_gemm3+rope"   # bf16 weights: the row-resident kernel at every row count
         assert counts.get(rope, 0) == 2, counts
     for u in range(2):
         want_ml = om.latent_to_mimi(x[u])
@@ -65,6 +68,70 @@ def test_transformer_output_against_the_oracle(pkg, mimi_full, frames):
         want = om.mimi_transformer(want_ml)
         parity(f"a17 transformer_out {dtype} rows={16 * frames} [{u}]", xf[u], want, XF_TOL, rel_floor=XF_FLOOR)
         parity(f"a17 pcm {dtype} T={frames} [{u}]", pcm[u], om.mimi_decode(want_ml), (2e-4, 5e-2))
+
+
+def _rope_tables(n, hd=64, max_period=10000.0):
+    """buildRoPE (flow_transformer.go:797-832; the decoder transformer's tables: mimi.go:498): f64 trig, stored f32"""
+    half = hd // 2
+    inv = 1.0 / np.power(max_period, np.arange(half, dtype=np.float64) / half)
+    ang = np.arange(n, dtype=np.float64)[:, None] * inv[None, :]
+    return np.cos(ang).astype(np.float32), np.sin(ang).astype(np.float32)
+
+
+def _layer_tensors(path, layer):
+    st = O.Store.open(path)
+    p = f"mimi.decoder_transformer.transformer.layers.{layer}."
+    return {k: st.tensor(p + k) for k in ("norm1.weight", "norm1.bias", "norm2.weight", "norm2.bias", "self_attn.in_proj.weight", "linear1.weight",
+                                          "linear2.weight", "layer_scale_2.scale")}
+
+
+@pytest.mark.parametrize("rows,pos0,per_seg", [(1, 0, 0), (16, 5, 0), (64, 0, 64), (100, 3, 50), (640, 0, 320), (2000, 0, 2000), (4099, 7, 0)])
+def test_layer_piece_qkv_against_the_oracle_ops(pkg, mimi_full, rows, pos0, per_seg):
+    """norm1 + in_proj + RoPE of q and k through the kernel the decoder launches for it (bf16 weights: k_mimi_rowlin, the row-resident fused kernel;
+    f32 weights: LayerNorm launch + k_gemm3/k_gemm2 with the RoPE epilogue) against the oracle's own LayerNorm (f64 statistics, linear.go:295-309),
+    Linear (the reference's row-dot order) and RoPE (rope.go:81-105) on the file's weights: every row count class -- one row, one tile, a partial last
+    block, several segments whose positions restart, thousands of rows."""
+    dtype, om, gm = mimi_full
+    rng = np.random.default_rng(rows + pos0)
+    x = (rng.standard_normal((rows, 512)) * 1.5 + 0.2).astype(np.float32)
+    cos, sin = _rope_tables(8192)
+    for layer in (0, 1):
+        t = _layer_tensors(gm.path, layer)
+        pkg.runtime.launch_counts(True)
+        got = gm.mimi_layer_qkv(layer, x, pos0, per_seg)
+        counts = pkg.runtime.launch_counts(False)
+        if dtype == "BF16":
+            assert counts.get("k_mimi_rowlin+rope", 0) == 1 and "k_layernorm_reg" not in counts and "k_layernorm" not in counts, counts
+        y = O.linear(O.layernorm(x, t["norm1.weight"], t["norm1.bias"], 1e-5), t["self_attn.in_proj.weight"])
+        want = y.copy()
+        seg = per_seg if per_seg else rows
+        for part in (0, 1):   # q and k: 8 heads x 64, rotated at the row's position; v is left alone
+            blk = y[:, part * 512:(part + 1) * 512].reshape(rows, 8, 64)
+            for r0 in range(0, rows, seg):
+                n = min(seg, rows - r0)
+                # O.rope rotates [prefix, seq, dim] at positions pos .. pos + seq - 1: heads as the prefix
+                rot = O.rope(np.ascontiguousarray(blk[r0:r0 + n].transpose(1, 0, 2)), cos, sin, pos0)
+                want[r0:r0 + n, part * 512:(part + 1) * 512] = rot.transpose(1, 0, 2).reshape(n, 512)
+        parity(f"a17 layer piece qkv {dtype} layer {layer} rows={rows} pos0={pos0} seg={per_seg}", got, want, (1e-4, 5e-3), rel_floor=XF_FLOOR)
+
+
+@pytest.mark.parametrize("rows", [1, 16, 63, 64, 65, 640, 4099])
+def test_layer_piece_ffn_against_the_oracle_ops(pkg, mimi_full, rows):
+    """x + layer_scale_2 * linear2(gelu(linear1(norm2(x)))) through the kernel the decoder launches for it (bf16 weights: k_mimi_ffn) against the
+    oracle's LayerNorm, Linear and GELU(erf) (tensor_util.go:84-94) on the file's weights."""
+    dtype, om, gm = mimi_full
+    rng = np.random.default_rng(rows)
+    x = (rng.standard_normal((rows, 512)) * 1.5 + 0.2).astype(np.float32)
+    for layer in (0, 1):
+        t = _layer_tensors(gm.path, layer)
+        pkg.runtime.launch_counts(True)
+        got = gm.mimi_layer_ffn(layer, x)
+        counts = pkg.runtime.launch_counts(False)
+        if dtype == "BF16":
+            assert counts.get("k_mimi_ffn", 0) == 1 and "k_layernorm_reg" not in counts, counts
+        h = O.gelu_erf(O.linear(O.layernorm(x, t["norm2.weight"], t["norm2.bias"], 1e-5), t["linear1.weight"]))
+        want = x + t["layer_scale_2.scale"].reshape(1, -1) * O.linear(h, t["linear2.weight"])
+        parity(f"a17 layer piece ffn {dtype} layer {layer} rows={rows}", got, want, (1e-4, 5e-3), rel_floor=XF_FLOOR)
 
 
 def test_a_wrong_window_would_fail(pkg, mimi_full):
@@ -97,7 +164,7 @@ def test_wide_batch_takes_the_fused_feed_forward(pkg, mimi_full):
     pkg.runtime.launch_counts(True)
     _, ml, xf = gm.decode_stages(x)
     counts = pkg.runtime.launch_counts(False)
-    rope = "k_gemm5+rope" if dtype == "BF16" else "k_gemm3+rope"       # k_gemm5 takes bf16 weights from 1024 rows
+    rope = "k_mimi_rowlin+rope" if dtype == "BF16" else "k_gemm3+rope"
     assert counts.get("k_attn_window", 0) == 2 and counts.get(rope, 0) == 2, counts
     assert counts.get("k_mimi_ffn", 0) == (2 if dtype == "BF16" else 0), counts
     for u in (0, 7, 15):
@@ -164,10 +231,10 @@ def test_wide_batch_equals_the_single_utterance_path_bit_for_bit(pkg, mimi_full)
     _, _, xf = gm.decode_stages(x)
     counts = pkg.runtime.launch_counts(False)
     if dtype == "BF16":
-        assert counts.get("k_gemm5+rope", 0) == 2 and counts.get("k_mimi_ffn", 0) == 2, counts
+        assert counts.get("k_mimi_rowlin+rope", 0) == 2 and counts.get("k_mimi_ffn", 0) == 2, counts
     for u in (0, 9, 15):
         pkg.runtime.launch_counts(True)
         _, _, one = gm.decode_stages(np.ascontiguousarray(x[u:u + 1, :48]))
         c1 = pkg.runtime.launch_counts(False)
-        assert c1.get("k_gemm3+rope", 0) == 2 and "k_gemm5+rope" not in c1, c1
+        assert c1.get("k_mimi_rowlin+rope" if dtype == "BF16" else "k_gemm3+rope", 0) == 2 and "k_gemm5+rope" not in c1, c1
         assert np.array_equal(xf[u][:48 * 16], one[0]), (u, float(np.abs(xf[u][:48 * 16] - one[0]).max()))

@@ -15,5 +15,6 @@ wl = bench.WORKLOADS["b64_10s_bf16"]
 path = bench.checkpoint_path(pkg, wl["file"], 0, lambda: None)
 model = pkg.Model.open(path, device=0, weights=wl["weights"], kv=wl["kv"], max_batch=64)
 lat = (np.random.default_rng(3).standard_normal((64, 125, 32)) * 0.5).astype(np.float32)
-pcm = model.decode_latents(lat)
+for _ in range(int(os.environ.get("PTTS_PMC_REPS", "1"))):
+    pcm = model.decode_latents(lat)
 print("decoded", pcm.shape, float(np.abs(pcm).max()))

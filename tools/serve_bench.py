@@ -43,7 +43,8 @@ for m_, v_ in zip(models, voices):
     wc = pkg.RuntimeGenerateConfig(max_steps=FRAMES, eos_threshold=float("inf"), frames_after_eos=3, device_voice=v_, pcm16=True)
     m_.generate_batch(prompts[:64], [wc] * 64)
 for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
-    disp = pkg.Dispatcher(models, max_batch=64, window_us=window_us, continuous=continuous, cont_kv_capacity=512, cont_max_steps=256)
+    disp = pkg.Dispatcher(models, max_batch=64, window_us=window_us, continuous=continuous, cont_kv_capacity=512, cont_max_steps=256,
+                          cont_steps_per_group=int(os.environ.get("PTTS_CONT_GROUP", "0")))
     lat, frames_done = [], []
     lock = threading.Lock()
 
