@@ -82,6 +82,7 @@ struct ContEngine {
     std::unique_lock<std::mutex> hold;    // the model's mutex, held while the engine has work in flight
     bool use_graph = false;
     int64_t admissions = 0, admitted = 0;
+    int64_t steps_run = 0, slot_steps = 0;   // AR steps launched; utterances stepping in them, summed (their ratio: mean occupancy)
 
     explicit ContEngine(Model& model) : m(model) {}
     ~ContEngine() {
@@ -159,6 +160,7 @@ void cont_destroy(ContEngine* e) { delete e; }
 int cont_free_slots(const ContEngine& e) { return e.free_slots(); }
 int cont_busy(const ContEngine& e) { return e.busy(); }
 void cont_counts(const ContEngine& e, int64_t* admissions, int64_t* admitted) { *admissions = e.admissions; *admitted = e.admitted; }
+void cont_occupancy(const ContEngine& e, int64_t* steps, int64_t* slot_steps) { *steps = e.steps_run; *slot_steps = e.slot_steps; }
 
 bool cont_accepts(const ContEngine& e, const ptts_request& r) {
     if (r.step_callback || r.pcm_callback || r.lsd_steps > 1) return false;
@@ -455,6 +457,7 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
             if (e.use_graph) enqueue_step(b, 1, true, steps);
             else for (int k = 0; k < steps; k++) enqueue_step(b, 1, false, 1);
             e.seq++;
+            e.steps_run += steps; e.slot_steps += (int64_t)steps * e.n_gen;
             ContEngine::Snap& sn = e.snaps[e.seq & 1];
             if (sn.pending) take_snapshot(e, sn, done);   // (cannot happen: the older read-back is consumed every turn)
             PTTS_HIP(hipMemcpyAsync(sn.host, b.st.active, (size_t)5 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));

@@ -55,6 +55,7 @@ struct Dispatcher {
     // statistics
     int64_t n_requests = 0, n_batches = 0, n_cancelled_waiting = 0, max_depth = 0;
     double sum_wait_us = 0.0, sum_exec_us = 0.0;
+    int64_t cont_steps = 0, cont_slot_steps = 0;   // continuous engines: AR steps launched, utterances stepping in them (summed)
 
     void run(int w);
     void run_continuous(int w);
@@ -248,11 +249,15 @@ void Dispatcher::run_continuous(int w) {
                 take.clear();
             }
             std::vector<void*> done;
+            int64_t st0 = 0, ss0 = 0, st1 = 0, ss1 = 0;
+            cont_occupancy(*eng, &st0, &ss0);
             cont_advance(*eng, cont_group, done, false);
+            cont_occupancy(*eng, &st1, &ss1);
             const double exec_us = std::chrono::duration<double, std::micro>(Clock::now() - t0).count();
             if (!done.empty() || exec_us > 0) {
                 std::lock_guard<std::mutex> lock(mu);
                 sum_exec_us += exec_us;
+                cont_steps += st1 - st0; cont_slot_steps += ss1 - ss0;
                 for (void* t : done) {
                     DispatchItem* d = static_cast<DispatchItem*>(t);
                     d->rc = d->res->status;
@@ -354,6 +359,7 @@ void dispatcher_stats(Dispatcher* d, ptts_dispatch_stats* out) {
     out->max_queue_depth = d->max_depth;
     out->mean_batch = d->n_batches ? (double)d->n_requests / (double)d->n_batches : 0.0;
     out->mean_wait_us = d->n_requests ? d->sum_wait_us / (double)d->n_requests : 0.0;
+    out->cont_steps = d->cont_steps; out->cont_slot_steps = d->cont_slot_steps;
     out->mean_exec_us = d->n_batches ? d->sum_exec_us / (double)d->n_batches : 0.0;
 }
 

@@ -281,7 +281,7 @@ bool gemm5_supported(const GemmArgs& a) {
     if (a.win_taps && (a.win_taps < 2 || a.win_c % 64 || a.K != a.win_taps * a.win_c || a.kslice)) return false;
     const bool res = a.epi >= EPI_RESADD;
     const bool epi_ok = a.epi == EPI_NONE || a.epi == EPI_GELU || a.epi == EPI_ELU || a.epi == EPI_RESADD || a.epi == EPI_SCALE_RESADD || a.epi == EPI_RESADD_ELU;
-    static const int min_m = [] { const char* e = getenv("PTTS_GEMM5_MIN_M"); return e ? atoi(e) : 1024; }();   // A/B measurement (16384: the decoder at many rows only)
+    constexpr int min_m = 1024;
     return a.w_bf16 && epi_ok && a.M >= min_m && a.K % 64 == 0 && a.K >= 64 && a.N % 128 == 0 && !a.tail &&
            (!a.kslice || (a.kslice % 64 == 0 && a.K % a.kslice == 0 && a.epi == EPI_NONE && !a.bias && !a.rope_cos && a.zstride % 4 == 0)) &&
            aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0 && a.ldw % 8 == 0 && aligned16(a.W) && (int64_t)a.N * a.ldw * 2 >= (int64_t)a.N * 4 &&

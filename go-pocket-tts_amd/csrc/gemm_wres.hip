@@ -176,8 +176,7 @@ static bool wres_common(const GemmArgs& a) {
 static int wres_shape(const GemmArgs& a) {   // 1: 256 x 256 tile, 2: 128 columns x 512 k, 0: not this kernel's
     if (!wres_common(a)) return 0;
     if (a.K <= 256 && a.K > 128 && a.N <= 256 && a.N > 128) return 1;              // (narrower shapes would multiply zero padding)
-    static const int wide_k = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 2; }();   // 1: without the K = 512 shapes (A/B measurement)
-    if (wide_k >= 2 && a.K <= 512 && a.K > 256 && a.N >= 512 && (a.N + 127) / 128 <= 32 && a.M >= 16384) return 2;
+    if (a.K <= 512 && a.K > 256 && a.N >= 512 && (a.N + 127) / 128 <= 32 && a.M >= 16384) return 2;
     return 0;
 }
 bool gemm_wres_supported(const GemmArgs& a) { return wres_shape(a) != 0; }

@@ -60,6 +60,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
 };
+constexpr int kSkinnyChunkRows = 256;   // up to this many rows a GEMM on a step matrix runs as 64-row chunks of the step kernel (launch_gemm)
 void launch_gemm(const GemmArgs& a, hipStream_t stream);
 bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream);   // a product with the RoPE epilogue (GemmArgs::rope_cos) on k_gemm3; false: the shape is not taken (the caller rotates in a second launch)
 bool gemm_wres_supported(const GemmArgs& a);   // gemm_wres.hip: K, N <= 256 with the whole weight matrix resident in LDS

@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs a, int a_vec, int w_vec) 
 }
 
 bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream) {
-    static const int g5 = [] { const char* e = getenv("PTTS_GEMM5"); return e ? atoi(e) : 1; }();   // A/B measurement
-    if (g5 && gemm5_supported(a)) { launch_gemm5(a, stream); return true; }
+    if (gemm5_supported(a)) { launch_gemm5(a, stream); return true; }
     if (!gemm3_supported(a)) return false;
     launch_gemm3(a, stream);
     return true;
@@ -153,15 +152,31 @@ bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream) {
 
 void launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.M <= 0 || a.N <= 0) return;
-    static const int force = [] { const char* e = getenv("PTTS_GEMM"); return e ? atoi(e) : 0; }();   // A/B measurement only
     // a few rows (prefill of a short prompt, batch-1 serving): the step's weight-streaming kernel beats a tile GEMM that would
     // fill a handful of CUs
     if (a.M <= 64 && a.Wt && skinny_supported(a, 1)) { launch_skinny(a, SkinnyFuse{}, 1, nullptr, stream); return; }
-    static const int wres = [] { const char* e = getenv("PTTS_GEMM_WRES"); return e ? atoi(e) : 1; }();   // A/B measurement
-    if (wres && force != 2 && gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
-    static const int g5 = [] { const char* e = getenv("PTTS_GEMM5"); return e ? atoi(e) : 1; }();   // A/B measurement
-    if (g5 && force != 2 && gemm5_supported(a)) { launch_gemm5(a, stream); return; }
-    if (force != 2 && gemm3_supported(a)) { launch_gemm3(a, stream); return; }
+    // a few dozen to a few hundred rows (the prompt of a handful of newcomers joining a running batch): the same kernel over 64-row chunks -- each chunk
+    // streams the weights again (a few MB: 6-9 us), which the 128-row tile GEMMs below cannot match at these sizes (k_gemm2 / k_gemm: 90-120 us per
+    // launch at 75 rows in the serving trace of round 4, 17 % of the GPU's time while serving)
+    if (a.M <= kSkinnyChunkRows && a.Wt && !a.rope_cos && !a.kslice && !a.tail && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0) {
+        GemmArgs c = a;
+        c.M = 64;
+        if (skinny_supported(c, 1)) {
+            for (int m0 = 0; m0 < a.M; m0 += 64) {
+                c = a;
+                c.M = std::min(64, a.M - m0);
+                c.A = a.A + (int64_t)m0 * a.amap.ld;
+                c.C = a.C + (int64_t)m0 * a.cmap.ld;
+                if (a.R) c.R = a.R + (int64_t)m0 * a.cmap.ld;
+                if (a.gate) c.gate = a.gate + (int64_t)m0 * a.ldg;
+                launch_skinny(c, SkinnyFuse{}, 1, nullptr, stream);
+            }
+            return;
+        }
+    }
+    if (gemm_wres_supported(a)) { launch_gemm_wres(a, stream); return; }
+    if (gemm5_supported(a)) { launch_gemm5(a, stream); return; }
+    if (gemm3_supported(a)) { launch_gemm3(a, stream); return; }
     if (gemm2_supported(a)) { launch_gemm2(a, stream); return; }
     note_launch("k_gemm");
     int a_vec = aligned16(a.A) && a.amap.ld % 4 == 0 && a.amap.batch_stride % 4 == 0;

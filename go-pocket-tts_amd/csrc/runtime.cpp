@@ -448,10 +448,18 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets) {
         g1.epi = EPI_GELU;
         launch_gemm(g1, s);
         GemmArgs g2 = mk(m, pff, flat(d.ffn), L.l2, px, flat(D), R);
-        const int S = R <= 64 ? pick_split((int)R, D, d.ffn) : 1;
-        if (S > 1 && skinny_supported(g2, S)) {
+        const int S = R <= kSkinnyChunkRows ? pick_split(std::min(R, 64), D, d.ffn) : 1;
+        GemmArgs g2c = g2;
+        g2c.M = std::min(R, 64);
+        if (S > 1 && skinny_supported(g2c, S)) {   // (64-row chunks of the split step kernel; the planes of all chunks form one [S][R][D] operand)
             DevBuf& pb = m.work(9, (size_t)S * R * D * f);
-            launch_skinny(g2, SkinnyFuse{}, S, pb.as<float>(), s);
+            for (int r0 = 0; r0 < R; r0 += 64) {
+                g2c = g2;
+                g2c.M = std::min(64, R - r0);
+                g2c.A = g2.A + (int64_t)r0 * d.ffn;
+                g2c.zstride = (int64_t)R * D;
+                launch_skinny(g2c, SkinnyFuse{}, S, pb.as<float>() + (size_t)r0 * D, s);
+            }
             pend_partial = pb.as<float>(); pend_split = S; pend_bias = m.at<float>(L.l2.b);
         } else {
             // many rows, few row panels: a 4 d_model-deep product on ~100-200 blocks leaves one wave per SIMD waiting on its own
@@ -517,8 +525,7 @@ static int pick_split(int M, int N, int K, bool w_bf16) {
     if (K <= 1024) return 1;   // a whole-K block is one memory burst; splitting pays only when K forces several bursts
     // a full batch on bf16 weights: 2048-deep slices (k_skinny NJ = 8, 32-column blocks): the producer's blocks fetch a third more,
     // every consumer block of the next launch re-reads half as many planes
-    static const bool deep = [] { const char* e = getenv("PTTS_DEEP_SLICES"); return !e || atoi(e) != 0; }();   // A/B measurement
-    if (deep && w_bf16 && M > 32 && K >= 4096 && K % 2048 == 0 && ((N + 31) / 32) * ((M + 15) / 16) * (K / 2048) >= 200) return K / 2048;
+    if (w_bf16 && M > 32 && K >= 4096 && K % 2048 == 0 && ((N + 31) / 32) * ((M + 15) / 16) * (K / 2048) >= 200) return K / 2048;
     int need = (K + 1023) / 1024;
     int blocks = ((N + 63) / 64) * ((M + 15) / 16);
     int want = (256 + blocks - 1) / blocks;
@@ -915,8 +922,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs g = mk(m, w.up + (size_t)r0 * C, seg(C, rn, up_bs), d.init_conv, w.c0 + (size_t)(w.Ps[0] + r0) * ch,
                         seg(ch, rn, (int64_t)(w.Ps[0] + w.Ls[0]) * ch), B * rn);
         g.epi = EPI_ELU;  // x = elu(initConv(x))
-        static const int kperm = [] { const char* e = getenv("PTTS_CONV_KPERM"); return e ? atoi(e) : 1; }();   // A/B measurement
-        if (kperm && C % 64 == 0 && d.init_conv.in == d.init_k * C) { g.win_taps = d.init_k; g.win_c = C; }
+        if (C % 64 == 0 && d.init_conv.in == d.init_k * C) { g.win_taps = d.init_k; g.win_c = C; }   // (k walked channel-block-major: gemm5.hip)
         launch_gemm(g, s);
     }
     bool final_done = false;
@@ -934,7 +940,6 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         // elu(x) precedes every transposed conv: c0 was activated in the initConv epilogue, uo[j-1] in its residual epilogue
         if (j == 2 && d.rb1[j].wf != NONE && d.rb2[j].wf != NONE && d.rb1[j].bf16 && d.rb2[j].bf16 && d.up[j].wf != NONE) {
             // the last stage as ONE kernel: transposed convolution + residual block + final convolution (resblock_up.hip); u[2] is never written
-            static const int want = [] { const char* e = getenv("PTTS_FUSE_UP"); return e ? atoi(e) : 1; }();   // A/B measurement
             ResArgs rr;
             rr.u = u; rr.u_bs = u_bs; rr.pad = Pout; rr.uo = uo;
             rr.w1 = m.at<uint8_t>(d.rb1[j].wf); rr.b1 = m.at<float>(d.rb1[j].b);
@@ -945,7 +950,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
             rr.pcm = pcm; rr.pcm_bs = w.Ls[3]; rr.pcm_rows = pcm_rows;
             rr.fuse_up = 1; rr.xin = in; rr.x_bs = in_bs; rr.x_pad = Pin; rr.x_L = Lin_; rr.CI = cin; rr.up_stride = st;
             rr.wup = m.at<uint8_t>(d.up[j].wf); rr.bup = m.at<float>(d.up[j].b);
-            if (want && resblock_up_supported(rr)) {
+            if (resblock_up_supported(rr)) {
                 launch_resblock_up(rr, s);
                 if (rows_used && pcm_rows) *rows_used = true;
                 final_done = true;
@@ -988,10 +993,7 @@ void mimi_range(Model& m, MimiWs& w, const float* lat, int64_t lat_bstride, int 
         GemmArgs g1 = mk(m, u + (size_t)(Pout - (d.rb_k1[j] - 1) + r0) * cout, seg(cout, rn, u_bs), d.rb1[j],
                          hb + (size_t)(Ph + r0) * hid, seg(hid, rn, h_bs), B * rn);
         g1.aop = AOP_ELU; g1.epi = EPI_ELU;
-        {
-            static const int kperm = [] { const char* e = getenv("PTTS_CONV_KPERM"); return e ? atoi(e) : 1; }();   // A/B measurement
-            if (kperm && cout % 64 == 0 && d.rb1[j].in == d.rb_k1[j] * cout) { g1.win_taps = d.rb_k1[j]; g1.win_c = cout; }
-        }
+        if (cout % 64 == 0 && d.rb1[j].in == d.rb_k1[j] * cout) { g1.win_taps = d.rb_k1[j]; g1.win_c = cout; }
         launch_gemm(g1, s);
         GemmArgs g2 = mk(m, hb + (size_t)r0 * hid, seg(hid, rn, h_bs), d.rb2[j], uo + (size_t)(Pout + r0) * cout, seg(cout, rn, u_bs), B * rn);
         g2.R = u + (size_t)(Pout + r0) * cout; g2.epi = EPI_RESADD_ELU;
@@ -1163,8 +1165,7 @@ void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps) {
     // plain launches: the previous step's last launch normally opened this one (b.opened); whoever changes a slot between two steps
     // (batch_reset, admission of a newcomer, the staged API) clears the flag, and k_step_begin opens the step for every row
     if (!b.opened) step_open(b);
-    static const bool fuse = [] { const char* e = getenv("PTTS_FUSE_FINISH"); return !e || atoi(e) != 0; }();   // A/B measurement
-    if (!step_core(b, lsd, b.opened, fuse, fuse && chain_steps()))   // the bookkeeping normally rides in the step's last launch
+    if (!step_core(b, lsd, b.opened, true, chain_steps()))   // the bookkeeping rides in the step's last launch (shapes it does not take: k_step_finish)
         launch_step_finish(b.st, b.cur_now(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
 }
 
@@ -1514,9 +1515,8 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         };
         // Whole batch decoded in one go (the default): the decoder's last kernel stores every utterance's samples straight into
         // its page-locked result buffer (f32 or int16) -- the kernel's stores ARE the device->host transfer: no device PCM buffer,
-        // no copies, no copy kernels competing with the decoder.  PTTS_PCM_DIRECT=0: device buffer + copies (A/B measurement).
-        static const bool env_direct = [] { const char* e = getenv("PTTS_PCM_DIRECT"); return !e || atoi(e) != 0; }();
-        const bool try_direct = env_direct && !streaming && f_done == 0;
+        // no copies, no copy kernels competing with the decoder.
+        const bool try_direct = !streaming && f_done == 0;
         const PcmRow* d_rows = nullptr;
         if (try_direct) {
             PcmRow* rows = b.rows_pinned;

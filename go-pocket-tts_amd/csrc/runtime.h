@@ -262,6 +262,7 @@ int cont_busy(const ContEngine& e);                               // utterances 
 bool cont_admit_now(const ContEngine& e, int waiting);              // admission pacing: see continuous.cpp
 void cont_admit(ContEngine& e, const ptts_request* const* reqs, ptts_result* const* results, void* const* tags, int n);
 void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain);
+void cont_occupancy(const ContEngine& e, int64_t* steps, int64_t* slot_steps);   // AR steps launched so far; utterances stepping in them, summed
 void cont_abort(ContEngine& e, int code, std::vector<void*>& done);
 
 // request dispatcher (dispatcher.cpp)

@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
             int m = m0 + q * 4 + reg;
             float v = acc[reg] * e_ws;
             if (z == 0 && a.R) v = e_r[reg] + (v + e_bias);
-            if (m < p_m && n_ok) partial[((int64_t)z * p_m + m) * p_n + n] = v;
+            if (m < p_m && n_ok) partial[(int64_t)z * (a.zstride ? a.zstride : (int64_t)p_m * p_n) + (int64_t)m * p_n + n] = v;   // (zstride: the planes of a row CHUNK of a taller operand)
         }
         return;
     }

@@ -885,7 +885,7 @@ class _DispatchOpts(C.Structure):
 
 class _DispatchStats(C.Structure):
     _fields_ = [("requests", C.c_int64), ("batches", C.c_int64), ("cancelled_waiting", C.c_int64), ("max_queue_depth", C.c_int64),
-                ("mean_batch", C.c_double), ("mean_wait_us", C.c_double), ("mean_exec_us", C.c_double), ("reserved", C.c_int64 * 2)]
+                ("mean_batch", C.c_double), ("mean_wait_us", C.c_double), ("mean_exec_us", C.c_double), ("cont_steps", C.c_int64), ("cont_slot_steps", C.c_int64)]
 
 
 DISPATCH_EXEC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(_Request), C.c_int32, C.POINTER(_Result), C.c_void_p, C.c_int32)

@@ -251,7 +251,7 @@ typedef struct ptts_dispatch_opts {
 typedef struct ptts_dispatch_stats {
     int64_t requests, batches, cancelled_waiting, max_queue_depth;
     double  mean_batch, mean_wait_us, mean_exec_us;
-    int64_t reserved[2];
+    int64_t cont_steps, cont_slot_steps;   /* continuous batching: AR steps launched; utterances stepping in them, summed (ratio = mean occupied slots) */
 } ptts_dispatch_stats;
 int  ptts_dispatcher_create(ptts_model* const* models, int32_t n_models, const ptts_dispatch_opts* opts, ptts_dispatcher** out);
 /* queueing logic over a caller-supplied executor (no GPU involved): unit tests of the coalescing / cancellation rules */

@@ -19,4 +19,5 @@ for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
     print(f"{k[:60]:60s} n={v[0]:8d} total={v[1]/1e6:10.2f} ms avg={v[1]/v[0]/1e3:9.1f} us {100*v[1]/tot:5.1f}%")
 PY
 cat gpurun_out/${1}_serve_by_kernel.txt
+python3 tools/serve_timeline.py "$(ls gpurun_out/${1}_tr/*kernel_trace.csv | head -1)" > gpurun_out/${1}_serve_timeline.txt 2>&1; cat gpurun_out/${1}_serve_timeline.txt
 rm -f gpurun_out/${1}_tr/*kernel_trace.csv

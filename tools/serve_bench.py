@@ -78,7 +78,8 @@ for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
     lat.sort()
     print(f"engines {n_eng} {'continuous' if continuous else 'batch-at-a-time'} {'mixed 2-12 s' if mixed else '10 s'} clients {clients:4d}  window {window_us} us  {audio/wall:8.1f} x real time  latency p50 {1e3*statistics.median(lat):7.1f} ms  "
           f"p95 {1e3*lat[int(0.95*(len(lat)-1))]:7.1f} ms  batches {st['batches'] - st0['batches']:3d}  mean batch {(st['requests'] - st0['requests']) / max(1, st['batches'] - st0['batches']):5.1f}  "
-          f"mean queue wait {st['mean_wait_us']/1e3:6.1f} ms", flush=True)
+          f"mean queue wait {st['mean_wait_us']/1e3:6.1f} ms"
+          + (f"  steps {st['cont_steps'] - st0['cont_steps']} at {1e6*wall/max(1, st['cont_steps'] - st0['cont_steps']):.0f} us, mean occupancy {(st['cont_slot_steps'] - st0['cont_slot_steps'])/max(1, st['cont_steps'] - st0['cont_steps']):.1f}" if continuous else ""), flush=True)
     disp.close()
 for v in voices:
     v.close()
