@@ -63,7 +63,7 @@ struct ContEngine {
     DevBuf stage;                         // [2 B rows][max_steps][ldim]
     std::vector<int> stage_free;
     // newcomers whose voice ingestion and prefill are running on the I/O stream; they start stepping once that is done
-    struct Joining { hipEvent_t ready = nullptr; std::vector<int> slots; int ring = 0; };
+    struct Joining { hipEvent_t ready = nullptr; std::vector<int> slots; int ring = 0; uint64_t seq = 0; };
     std::deque<Joining> joining;
     hipStream_t io = nullptr;
     DevBuf adm_dev[4];
@@ -78,10 +78,20 @@ struct ContEngine {
     UploadArena arenas[2];
     hipEvent_t arena_free[2] = {nullptr, nullptr};
     int arena_turn = 0;
-    hipEvent_t ev_steps = nullptr, ev_gather = nullptr;
+    hipEvent_t ev_steps = nullptr;
+    DevBuf lat[2];                        // the frames of the utterances being decoded, gathered from their staging rows: two decodes' worth, in turn
+    hipEvent_t lat_free[2] = {nullptr, nullptr};
+    bool lat_busy[2] = {false, false};
+    int lat_turn = 0;
     std::unique_lock<std::mutex> hold;    // the model's mutex, held while the engine has work in flight
     bool use_graph = false;
     int64_t admissions = 0, admitted = 0;
+    // (measurement: PTTS_CONT_TRACE=<file> -- one line per group of steps: gap in front of it and its duration on the step stream, what ran beside it)
+    struct GroupRec { hipEvent_t t0, t1; int n_gen, steps, admitted, decodes_started, decoding, joining; };
+    std::vector<GroupRec> trace;
+    const char* trace_path = getenv("PTTS_CONT_TRACE");
+    int tr_admitted = 0, tr_decodes = 0;
+    int64_t tr_frames = 0, tr_padded = 0, tr_subs = 0;   // decoded frames, frames incl. padding to the sub-group's longest, sub-groups
     int64_t steps_run = 0, slot_steps = 0;   // AR steps launched; utterances stepping in them, summed (their ratio: mean occupancy)
 
     explicit ContEngine(Model& model) : m(model) {}
@@ -89,11 +99,25 @@ struct ContEngine {
         (void)hipStreamSynchronize(m.stream);
         (void)hipStreamSynchronize(m.stream2);
         if (io) { (void)hipStreamSynchronize(io); (void)hipStreamDestroy(io); }
+        if (trace_path && !trace.empty()) {
+            if (FILE* f = fopen(trace_path, "a")) {
+                fprintf(f, "# gap_us dur_us n_gen steps admitted decodes_started decoding joining\n");
+                for (size_t i = 0; i < trace.size(); i++) {
+                    float gap = 0.f, dur = 0.f;
+                    if (i > 0) (void)hipEventElapsedTime(&gap, trace[i - 1].t1, trace[i].t0);
+                    (void)hipEventElapsedTime(&dur, trace[i].t0, trace[i].t1);
+                    fprintf(f, "%.1f %.1f %d %d %d %d %d %d\n", 1e3 * gap, 1e3 * dur, trace[i].n_gen, trace[i].steps, trace[i].admitted, trace[i].decodes_started, trace[i].decoding, trace[i].joining);
+                }
+                fprintf(f, "# decoded frames %lld, with padding %lld, in %lld decodes\n", (long long)tr_frames, (long long)tr_padded, (long long)tr_subs);
+                fclose(f);
+            }
+            for (auto& g : trace) { (void)hipEventDestroy(g.t0); (void)hipEventDestroy(g.t1); }
+        }
         for (auto& j : joining) if (j.ready) (void)hipEventDestroy(j.ready);
         for (auto& p : decoding) if (p.done) (void)hipEventDestroy(p.done);
         for (hipEvent_t e : free_events) (void)hipEventDestroy(e);
         if (ev_steps) (void)hipEventDestroy(ev_steps);
-        if (ev_gather) (void)hipEventDestroy(ev_gather);
+        for (hipEvent_t ev : lat_free) if (ev) (void)hipEventDestroy(ev);
         for (Snap& sn : snaps) { if (sn.host) (void)hipHostFree(sn.host); if (sn.ready) (void)hipEventDestroy(sn.ready); }
         for (int i = 0; i < 2; i++) { if (arenas[i].base) (void)hipHostFree(arenas[i].base); if (arena_free[i]) (void)hipEventDestroy(arena_free[i]); }
         b.reset();
@@ -131,7 +155,8 @@ ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
     b.has_noise = true;
     e->slots.assign((size_t)slots, ContEngine::Slot{});
     for (ContEngine::Snap& sn : e->snaps) {
-        PTTS_HIP(hipHostMalloc((void**)&sn.host, sizeof(int32_t) * 5 * (size_t)slots, hipHostMallocDefault));
+        PTTS_HIP(hipHostMalloc((void**)&sn.host, sizeof(int32_t) * (5 * (size_t)slots + 1), hipHostMallocDefault));   // + the flow-cluster fault word
+        sn.host[5 * (size_t)slots] = 0;
         PTTS_HIP(hipEventCreateWithFlags(&sn.ready, hipEventDisableTiming));
     }
     for (int i = 0; i < 2; i++) PTTS_HIP(hipEventCreateWithFlags(&e->arena_free[i], hipEventDisableTiming));
@@ -142,7 +167,8 @@ ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
     e->stage.ensure((size_t)2 * slots * b.max_steps * m.d.ldim * sizeof(float));
     for (int i = 2 * slots - 1; i >= 0; i--) e->stage_free.push_back(i);
     PTTS_HIP(hipEventCreateWithFlags(&e->ev_steps, hipEventDisableTiming));
-    PTTS_HIP(hipEventCreateWithFlags(&e->ev_gather, hipEventDisableTiming));
+    for (hipEvent_t& ev : e->lat_free) PTTS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    for (DevBuf& l : e->lat) l.ensure((size_t)2 * slots * (size_t)max_steps * m.d.ldim * sizeof(float));   // every staging row at full length
     m.tcomb_for(1);
     // the decoder's workspaces at their largest, so that a later, bigger group of finished utterances never reallocates a buffer an
     // earlier group's kernels are still using
@@ -277,11 +303,13 @@ void cont_admit(ContEngine& e, const ptts_request* const* reqs, ptts_result* con
         j.slots.push_back(slot_of[(size_t)i]);
     }
     j.ready = e.event();
+    j.seq = e.seq;
     PTTS_HIP(hipEventRecord(j.ready, s));
     PTTS_HIP(hipEventRecord(e.arena_free[turn], s));   // (the requests' own host arrays stay valid until their callers are woken)
     e.joining.push_back(std::move(j));
     e.admissions++;
     e.admitted += n;
+    e.tr_admitted += n;
     e.last_admit_seq = e.seq;
 }
 
@@ -293,8 +321,13 @@ static void activate_ready(ContEngine& e, bool wait) {
         if (wait) PTTS_HIP(hipEventSynchronize(j.ready));
         else {
             hipError_t q = hipEventQuery(j.ready);
-            if (q == hipErrorNotReady) return;
-            if (q != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipEventQuery failed: %s", hipGetErrorString(q)));
+            if (q == hipErrorNotReady) {
+                // the prefill is still running beside the group in flight: the step STREAM waits for it (in front of the next group) rather than the host
+                // looking again a group later -- a newcomer idles one group less, at the price of a short stall of everyone when the prefill is the slower
+                static const int eager = tune("PTTS_CONT_EAGER", 0);
+                if (eager == 0 || (eager == 1 && j.seq == e.seq)) return;
+                PTTS_HIP(hipStreamWaitEvent(e.m.stream, j.ready, 0));
+            } else if (q != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipEventQuery failed: %s", hipGetErrorString(q)));
         }
         launch_slot_admit(b.st, b.pre_len.as<int32_t>(), b.pre_k.as<const void*>(), b.pre_v.as<const void*>(), e.adm_dev[j.ring].as<SlotAdmit>(), (int)j.slots.size(),
                           e.m.stream);
@@ -314,36 +347,57 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
     const int ld = d.ldim;
     const int64_t spf = d.samples_per_frame;
     hipStream_t s = m.stream, s2 = m.stream2;
-    PTTS_HIP(hipEventRecord(e.ev_steps, s));            // the staging copies were queued on the AR stream
-    PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
+    e.tr_decodes += (int)fin.size();
     std::sort(fin.begin(), fin.end(), [](const ContEngine::Staged& x, const ContEngine::Staged& y) { return x.nf > y.nf; });   // like lengths together: less padding
-    size_t at = 0;
-    while (at < fin.size()) {
+    // sub-groups whose decode fits the workspace; their frames are gathered FIRST, all of them, and on the AR stream itself: the staging rows are that
+    // stream's (written by its copies, refilled by its copies: no other stream ever has to hand them back), and the gather is a few microseconds there.
+    // (Round 3 gathered on the decoder's stream and made the AR stream wait for the LAST sub-group's gather -- which sat behind the first sub-group's whole
+    // decode: every decode of more than kFramesPerDecode frames stopped the step chain for ~5 ms, a quarter of the engine's time; PTTS_CONT_TRACE.)
+    struct Sub { size_t at, end; int T; size_t off; };
+    std::vector<Sub> subs;
+    size_t total = 0;
+    for (size_t at = 0; at < fin.size();) {
         size_t end = at;
         int T = 0;
-        while (end < fin.size()) {   // a sub-group whose decode fits the workspace
+        while (end < fin.size()) {
             const int t2 = std::max(T, std::max(1, fin[end].nf));
             if (end > at && (int64_t)t2 * (int64_t)(end - at + 1) > kFramesPerDecode) break;
+            // (sorted by length: everything in the sub-group is padded to its first; a member much shorter than that starts the next one)
+            static const int band = tune("PTTS_CONT_BAND", 0);
+            if (band > 0 && end > at && fin[at].nf - fin[end].nf > std::max(band, fin[at].nf * band / 100)) break;
             T = t2; end++;
         }
-        const int nb = (int)(end - at);
-        DevBuf& lat = m.work(13, (size_t)nb * T * ld * sizeof(float));
-        PTTS_HIP(hipMemsetAsync(lat.p, 0, (size_t)nb * T * ld * sizeof(float), s2));
-        for (int i = 0; i < nb; i++) {
-            const ContEngine::Staged& f = fin[at + (size_t)i];
+        subs.push_back(Sub{at, end, T, total});
+        total += (end - at) * (size_t)T * ld;
+        e.tr_padded += (int64_t)(end - at) * T; e.tr_subs++;
+        for (size_t i = at; i < end; i++) e.tr_frames += fin[i].nf;
+        at = end;
+    }
+    const int lt = e.lat_turn;
+    e.lat_turn ^= 1;
+    DevBuf& lat_all = e.lat[lt];
+    if (e.lat_busy[lt]) PTTS_HIP(hipStreamWaitEvent(s, e.lat_free[lt], 0));   // the decode before last has read this buffer (long done)
+    lat_all.ensure(total * sizeof(float));
+    PTTS_HIP(hipMemsetAsync(lat_all.p, 0, total * sizeof(float), s));
+    for (const Sub& sb : subs)
+        for (size_t i = sb.at; i < sb.end; i++) {
+            const ContEngine::Staged& f = fin[i];
             if (f.nf > 0)
-                PTTS_HIP(hipMemcpyAsync(lat.as<float>() + (size_t)i * T * ld, e.stage.as<float>() + (size_t)f.row * b.max_steps * ld, (size_t)f.nf * ld * sizeof(float),
-                                        hipMemcpyDeviceToDevice, s2));
+                PTTS_HIP(hipMemcpyAsync(lat_all.as<float>() + sb.off + (i - sb.at) * (size_t)sb.T * ld, e.stage.as<float>() + (size_t)f.row * b.max_steps * ld,
+                                        (size_t)f.nf * ld * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
-        if (end == fin.size()) {   // the staging rows are read: the AR stream may refill them
-            PTTS_HIP(hipEventRecord(e.ev_gather, s2));
-            PTTS_HIP(hipStreamWaitEvent(s, e.ev_gather, 0));
-        }
+    PTTS_HIP(hipEventRecord(e.ev_steps, s));
+    PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
+    for (const Sub& sb : subs) {
+        const size_t at = sb.at, end = sb.end;
+        const int T = sb.T;
+        const int nb = (int)(end - at);
+        float* const lat = lat_all.as<float>() + sb.off;
         MimiWs mw;
         mimi_setup(m, mw, nb, T);
         mimi_zero_history(m, mw, s2);
         DevBuf& pcm = m.work(7, (size_t)nb * T * spf * sizeof(float));
-        mimi_range(m, mw, lat.as<float>(), (int64_t)T * ld, 0, T, pcm.as<float>(), nullptr, s2);
+        mimi_range(m, mw, lat, (int64_t)T * ld, 0, T, pcm.as<float>(), nullptr, s2);
         bool any_s16 = false;
         for (int i = 0; i < nb; i++) any_s16 |= fin[at + (size_t)i].req->pcm_format == PTTS_PCM_S16;
         DevBuf* s16 = nullptr;
@@ -372,7 +426,7 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
                 r.latents = (float*)malloc((size_t)std::max(1, nf) * ld * sizeof(float));
                 if (!r.latents) r.status = PTTS_ENOMEM;
                 else if (nf > 0)
-                    PTTS_HIP(hipMemcpyAsync(r.latents, lat.as<float>() + (size_t)i * T * ld, (size_t)nf * ld * sizeof(float), hipMemcpyDeviceToHost, s2));
+                    PTTS_HIP(hipMemcpyAsync(r.latents, lat + (size_t)i * T * ld, (size_t)nf * ld * sizeof(float), hipMemcpyDeviceToHost, s2));
             }
             p.tags.push_back(f.tag);
             p.res.push_back(f.res);
@@ -381,8 +435,9 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
         p.done = e.event();
         PTTS_HIP(hipEventRecord(p.done, s2));
         e.decoding.push_back(std::move(p));
-        at = end;
     }
+    PTTS_HIP(hipEventRecord(e.lat_free[lt], s2));
+    e.lat_busy[lt] = true;
     fin.clear();
 }
 
@@ -394,6 +449,7 @@ static void take_snapshot(ContEngine& e, ContEngine::Snap& sn, std::vector<void*
     const int B = e.B;
     PTTS_HIP(hipEventSynchronize(sn.ready));
     sn.pending = false;
+    if (sn.host[5 * (size_t)B]) { sn.host[5 * (size_t)B] = 0; flow_cluster_fault(b); }   // throws: the dispatcher fails everyone in flight and rebuilds the engine
     const int32_t* active = sn.host;
     const int32_t* n_frames = sn.host + 3 * (size_t)B;
     const int32_t* eos_step = sn.host + 4 * (size_t)B;
@@ -454,13 +510,22 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
                 if (so.busy && !so.joining) bound = std::max(bound, so.base_kv + std::min(so.ms, so.nf_seen + steps * (int)(e.seq - so.seen_seq)));
             }
             b.kv_bound = std::min(bound, e.cap);
+            ContEngine::GroupRec rec{};
+            if (e.trace_path) {
+                PTTS_HIP(hipEventCreate(&rec.t0)); PTTS_HIP(hipEventCreate(&rec.t1));
+                rec.n_gen = e.n_gen; rec.steps = steps; rec.admitted = e.tr_admitted; rec.decodes_started = e.tr_decodes; rec.decoding = (int)e.decoding.size(); rec.joining = (int)e.joining.size();
+                e.tr_admitted = e.tr_decodes = 0;
+                PTTS_HIP(hipEventRecord(rec.t0, s));
+            }
             if (e.use_graph) enqueue_step(b, 1, true, steps);
             else for (int k = 0; k < steps; k++) enqueue_step(b, 1, false, 1);
+            if (e.trace_path) { PTTS_HIP(hipEventRecord(rec.t1, s)); e.trace.push_back(rec); }
             e.seq++;
             e.steps_run += steps; e.slot_steps += (int64_t)steps * e.n_gen;
             ContEngine::Snap& sn = e.snaps[e.seq & 1];
             if (sn.pending) take_snapshot(e, sn, done);   // (cannot happen: the older read-back is consumed every turn)
             PTTS_HIP(hipMemcpyAsync(sn.host, b.st.active, (size_t)5 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            if (b.fc_ok) PTTS_HIP(hipMemcpyAsync(sn.host + 5 * (size_t)B, b.fc_fault(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
             PTTS_HIP(hipEventRecord(sn.ready, s));
             sn.seq = e.seq; sn.pending = true;
         }

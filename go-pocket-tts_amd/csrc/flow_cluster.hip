@@ -1,0 +1,306 @@
+// flow_cluster.hip -- the residual blocks of the flow net as one launch (the AR step's twelve 512 x 512 linears).
+#include <hip/hip_ext.h>
+
+#include "../../include/ptts.h"
+#include "common.h"
+#include "kernels.h"
+#include "device_util.h"
+
+namespace ptts {
+
+// ------------------------------------------------------------------------------------------------
+// flowResBlock.Forward x depth (flow_net.go:116-172):  h = silu(mlp0(modulate(LayerNorm(x), shift, scale)));  x += gate * mlp2(h)
+//
+// As launches (runtime.cpp step_core) these are 2 x depth dependent k_skinny launches of 4-5.6 us each for 0.5 MB of weights apiece: launch
+// boundary, a cold argument block, a cold weight round trip and the store drain every time.  Here the chain stays inside one launch:
+//   * a 16-row tile of the batch belongs to EIGHT workgroups; workgroup cb owns output columns [64 cb, 64 cb + 64) of every linear -- its weight
+//     fragments are requested one linear ahead (they depend on nothing) and wait in registers;
+//   * after each linear the eight exchange their 16 x 64 pieces so that each holds whole rows again (LayerNorm and the next product need them).
+//     The exchange is the guide's tagged granule: every value travels as one aligned 8-byte {value, tag} written by a single write-through (sc1)
+//     store, the reader sweeps its row with sc1 loads until all tags match -- the data is its own flag: no fence, no drain, no barrier on either
+//     side (cdna_hip_programming.md Guideline 16, R2; a row is 4 KB of granules);
+//   * tags count the exchanges of the tile across launches (a launch takes its base from a word in device memory that workgroup 0 of the tile
+//     advances at its end: every peer has read it by then, or it could not have published what workgroup 0 consumed last), so a granule left by an
+//     earlier exchange -- or an earlier launch, or an earlier replay of the same graph -- can never be taken for the awaited one; two buffers in
+//     turn (h / x), since a workgroup may publish exchange e + 1 while a peer still sweeps e;
+//   * every sweep is bounded; a sweep that gives up raises the fault word and the launch runs to its end on whatever it has (the host checks the word
+//     with the step counters and fails the batch).
+// The arithmetic is k_skinny's, instruction for instruction where it matters (the operand split, the k permutation of the fragment-ordered weights,
+// the order of the K-quarter sums, LayerNorm, epilogues), with the two MFMA operands exchanged so that a lane ends up with four consecutive columns
+// of one row (two 16-byte granule stores).
+// Work split inside a workgroup as in k_skinny: 16 waves; wave w stages row w of the tile (LayerNorm, split, LDS image); wave (cg = w & 3,
+// kq = w >> 2) multiplies 16 columns x K quarter kq; the quarters meet in LDS; waves kq == 0 run the epilogue and publish.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 fc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fc_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float fc_f32x2 __attribute__((ext_vector_type(2)));
+typedef float fc_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned fc_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FC_C = 512;                   // width of the flow net (host: flow_cluster_supported)
+constexpr int FC_RB = 2048, FC_CMASK = 127;   // LDS image: bytes and 16-byte chunks (- 1) per row (bf16 x 1024: k_skinny's NJ <= 4 image)
+constexpr unsigned FC_SPIN_LIMIT = 1u << 15;  // sweeps of a row before giving up (a pass is >= 0.5 us: >= 16 ms)
+constexpr int FC_FAULT_WORD = 32 * 8;
+
+union FcFrag {
+    fc_bf16x8 v;
+    uint4 q;
+};
+
+__device__ __forceinline__ void fc_split2(float a, float b, unsigned& hi, unsigned& lo) {   // (skinny.hip split2)
+    fc_f32x2 f = {a, b};
+    fc_bf16x2 h = __builtin_convertvector(f, fc_bf16x2);
+    fc_f32x2 r = f - __builtin_convertvector(h, fc_f32x2);
+    fc_bf16x2 l = __builtin_convertvector(r, fc_bf16x2);
+    hi = *reinterpret_cast<unsigned*>(&h);
+    lo = *reinterpret_cast<unsigned*>(&l);
+}
+
+// wave `wave`'s row of the LDS image from the lane's 2 x 4 values (columns 4 lane .. and 4 (lane + 64) ..)
+__device__ __forceinline__ void fc_stage(unsigned char* Xh, unsigned char* Xl, int wave, int lane, const float4 (&xr)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int k = (lane + 64 * j) * 4;
+        unsigned h01, l01, h23, l23;
+        fc_split2(xr[j].x, xr[j].y, h01, l01);
+        fc_split2(xr[j].z, xr[j].w, h23, l23);
+        const int off = wave * FC_RB + ((((k >> 3) ^ wave) & FC_CMASK) << 4) + ((k & 4) << 1);
+        *reinterpret_cast<uint2*>(&Xh[off]) = make_uint2(h01, h23);
+        *reinterpret_cast<uint2*>(&Xl[off]) = make_uint2(l01, l23);
+    }
+}
+
+// 16 columns (this wave's weight fragments) x 16 rows (the image) x K quarter kq: D[m = column][n = row], lane (n = lane & 15, q) holds columns 4q .. 4q+3
+__device__ __forceinline__ fc_f32x4 fc_mma(const unsigned char* Xh, const unsigned char* Xl, const uint4 (&w)[4], int kq, int q, int i16) {
+    fc_f32x4 acc_h = {0.f, 0.f, 0.f, 0.f}, acc_l = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int c = kq * 16 + q * 4 + s;
+        const int off = i16 * FC_RB + (((c ^ i16) & FC_CMASK) << 4);
+        FcFrag xh, xl, wv;
+        xh.q = *reinterpret_cast<const uint4*>(&Xh[off]);
+        xl.q = *reinterpret_cast<const uint4*>(&Xl[off]);
+        wv.q = w[s];
+        acc_h = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv.v, xh.v, acc_h, 0, 0, 0);
+        acc_l = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wv.v, xl.v, acc_l, 0, 0, 0);
+    }
+    return acc_h + acc_l;
+}
+
+// the lane's 8 values of its wave's row from the granule buffer, once every tag is `tag`.
+// Sixteen waves re-reading their whole rows (64 KB of granules per workgroup and pass) queue behind each other in the CU's own memory pipe -- the first cut
+// did that and a hop took 3 us (in-kernel stamps; the guide's handoff-1to1 row says as much for 15 streaming waves on the consumer CU).  So a wave WATCHES
+// two granule pairs of every producing wave (the ends of its second and fourth lane group's stores: 1 KB per wave and pass) and reads its row when those
+// have turned -- then checks every tag of what it read (the pairs it watched say nothing certain about their neighbours) and goes back to watching if one
+// is old.
+template <typename RS>
+__device__ __forceinline__ bool fc_sweep(RS rs, int row_off, int lane, unsigned tag, float4 (&xr)[2]) {
+    fc_u32x4 g0, g1, g2, g3;
+    bool got = true;
+    const int voff = row_off + lane * 32;
+    const int watch = row_off + ((lane >> 1) * 16 + 6 + 8 * (lane & 1)) * 8;   // producing wave lane >> 1 (16 columns each): its columns 6, 7 / 14, 15
+    for (unsigned spins = 0;;) {
+        asm volatile("" ::: "memory");   // (the loads are re-issued every pass)
+        const fc_u32x4 w = __builtin_amdgcn_raw_buffer_load_b128(rs, watch, 0, 16);   // aux 16: sc1
+        if (__all(w[1] == tag && w[3] == tag)) {
+            asm volatile("" ::: "memory");
+            g0 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 16);
+            g1 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 16, 0, 16);
+            g2 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 2048, 0, 16);
+            g3 = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + 2064, 0, 16);
+            const bool ok = g0[1] == tag && g0[3] == tag && g1[1] == tag && g1[3] == tag && g2[1] == tag && g2[3] == tag && g3[1] == tag && g3[3] == tag;
+            if (__all(ok)) break;
+        }
+        if (++spins > FC_SPIN_LIMIT) { got = false; g0 = g1 = g2 = g3 = fc_u32x4{0u, 0u, 0u, 0u}; break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    xr[0] = make_float4(__uint_as_float(g0[0]), __uint_as_float(g0[2]), __uint_as_float(g1[0]), __uint_as_float(g1[2]));
+    xr[1] = make_float4(__uint_as_float(g2[0]), __uint_as_float(g2[2]), __uint_as_float(g3[0]), __uint_as_float(g3[2]));
+    return got;
+}
+
+template <typename RS>
+__device__ __forceinline__ void fc_publish(RS rs, int voff, unsigned tag, const float (&v)[4]) {
+    const fc_u32x4 a = {__float_as_uint(v[0]), tag, __float_as_uint(v[1]), tag}, b = {__float_as_uint(v[2]), tag, __float_as_uint(v[3]), tag};
+    __builtin_amdgcn_raw_buffer_store_b128(a, rs, voff, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(b, rs, voff + 16, 0, 16);
+}
+
+template <bool STAMP>
+__global__ __launch_bounds__(1024) void k_flow_cluster(FlowClusterArgs a) {
+    // (measurement build, PTTS_FC_STAMPS: 100-MHz timestamps of wave 0 of every workgroup at the phase boundaries)
+#define FC_STAMP(i) do { if (STAMP && threadIdx.x == 0) a.stamps[blockIdx.x * 64 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    FC_STAMP(0);
+    __shared__ __attribute__((aligned(16))) unsigned char Xh[16 * FC_RB];
+    __shared__ __attribute__((aligned(16))) unsigned char Xl[16 * FC_RB];
+    __shared__ float4 red[3 * 4 * 64];   // [kq - 1][cg][lane]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cg = wave & 3, kq = wave >> 2, q = lane >> 4, i16 = lane & 15;
+    // workgroups that stream the same weight columns are 8-congruent in dispatch order (one XCD, one L2 copy of the weights: speed only)
+    const int cb = blockIdx.x & 7, tile = blockIdx.x >> 3;
+    const int m0 = tile * 16;
+    const bool row_ok = m0 + wave < a.rows;          // this wave's row of the tile exists (wave-uniform)
+    const int64_t mrow = row_ok ? m0 + wave : 0;
+    const bool st_wave = kq == 0;                    // this wave runs the epilogue of its 16 columns
+    const bool s_ok = m0 + i16 < a.rows;             // ... and this lane's row exists
+    const int64_t srow = s_ok ? m0 + i16 : 0;
+    const int scol = cb * 64 + cg * 16 + q * 4;
+    const int kc0 = lane * 4, kc1 = (lane + 64) * 4;
+
+    unsigned* const sync = a.sync + tile * 32;
+    const unsigned base = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    auto rs = __builtin_amdgcn_make_buffer_rsrc(a.xbuf + (size_t)tile * (2 * 16 * FC_C), 0, 2 * 16 * FC_C * 8, 0x00020000);
+    const int sweep_off = wave * (FC_C * 8);                  // the wave's row of granules
+    const int pub_off = i16 * (FC_C * 8) + scol * 8;          // the storing lane's four granules
+    constexpr int BUF1 = 16 * FC_C * 8;                       // second buffer (the h exchanges)
+
+    // this wave's weight fragments: tile of 16 columns x super-step kq of the fragment-ordered copy (model.cpp add_tiled: [tile][ss][4][64 lanes] x 16 B)
+    const int64_t wfrag = ((int64_t)((cb * 4 + cg) * 4 + kq) * 4) * 64 + lane;
+    uint4 wA[4], wB[4];
+    {
+        const uint4* s0 = reinterpret_cast<const uint4*>(a.w0[0]) + wfrag;
+        const uint4* s2 = reinterpret_cast<const uint4*>(a.w2[0]) + wfrag;
+#pragma unroll
+        for (int s = 0; s < 4; s++) wA[s] = s0[s * 64];
+#pragma unroll
+        for (int s = 0; s < 4; s++) wB[s] = s2[s * 64];
+    }
+    float4 res = make_float4(0.f, 0.f, 0.f, 0.f);   // the storing lane's piece of the residual stream, in registers across the blocks
+    if (st_wave) res = *reinterpret_cast<const float4*>(a.fx_in + srow * FC_C + scol);
+    unsigned fault = 0;
+
+#pragma unroll 1
+    for (int r = 0; r < a.depth; r++) {
+        const int rn = min(r + 1, a.depth - 1);
+        // ---------------- mlp0: rows = the residual stream, adaLN prologue ----------------
+        float4 bias0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st_wave) bias0 = *reinterpret_cast<const float4*>(a.b0[r] + scol);
+        if (row_ok) {
+            float4 xr[2];
+            const float* lnw = a.ln_w[r]; const float* lnb = a.ln_b[r];
+            const float* shift = a.ada + mrow * a.ldmod + (int64_t)(r * 3) * FC_C; const float* scale = shift + FC_C;
+            const float4 lw0 = *reinterpret_cast<const float4*>(lnw + kc0), lw1 = *reinterpret_cast<const float4*>(lnw + kc1);
+            const float4 lb0 = *reinterpret_cast<const float4*>(lnb + kc0), lb1 = *reinterpret_cast<const float4*>(lnb + kc1);
+            const float4 lc0 = *reinterpret_cast<const float4*>(scale + kc0), lc1 = *reinterpret_cast<const float4*>(scale + kc1);
+            const float4 lh0 = *reinterpret_cast<const float4*>(shift + kc0), lh1 = *reinterpret_cast<const float4*>(shift + kc1);
+            if (r == 0) {
+                xr[0] = *reinterpret_cast<const float4*>(a.fx_in + mrow * FC_C + kc0);
+                xr[1] = *reinterpret_cast<const float4*>(a.fx_in + mrow * FC_C + kc1);
+            } else if (!fc_sweep(rs, sweep_off, lane, base + 2 * r, xr)) fault = 1;
+            // LayerNorm over the row, biased variance (linear.go:295-309) -- k_skinny's prologue (PRO_LN | PRO_AFFINE | PRO_MOD)
+            fc_f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; j++) s2 += fc_f32x2{xr[j].x, xr[j].z} + fc_f32x2{xr[j].y, xr[j].w};
+            const float rk = __builtin_amdgcn_rcpf((float)FC_C);
+            const float mean = wave_sum_dpp(s2.x + s2.y) * rk;
+            const fc_f32x2 m2 = {mean, mean};
+            fc_f32x2 v2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const fc_f32x2 da = fc_f32x2{xr[j].x, xr[j].y} - m2, db = fc_f32x2{xr[j].z, xr[j].w} - m2;
+                v2 += da * da + db * db;
+            }
+            const float inv_std = __builtin_amdgcn_rsqf(wave_sum_dpp(v2.x + v2.y) * rk + a.eps[r]);
+            const fc_f32x2 is2 = {inv_std, inv_std};
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const float4 lw = j ? lw1 : lw0, lb = j ? lb1 : lb0, lc = j ? lc1 : lc0, lh = j ? lh1 : lh0;
+                fc_f32x2 oa = (fc_f32x2{xr[j].x, xr[j].y} - m2) * is2, ob = (fc_f32x2{xr[j].z, xr[j].w} - m2) * is2;
+                oa = oa * fc_f32x2{lw.x, lw.y} + fc_f32x2{lb.x, lb.y};
+                ob = ob * fc_f32x2{lw.z, lw.w} + fc_f32x2{lb.z, lb.w};
+                const fc_f32x2 one = {1.0f, 1.0f};
+                oa = oa * (fc_f32x2{lc.x, lc.y} + one) + fc_f32x2{lh.x, lh.y};
+                ob = ob * (fc_f32x2{lc.z, lc.w} + one) + fc_f32x2{lh.z, lh.w};
+                xr[j] = make_float4(oa.x, oa.y, ob.x, ob.y);
+            }
+            FC_STAMP(1 + 8 * r);
+            fc_stage(Xh, Xl, wave, lane, xr);
+        }
+        FC_STAMP(2 + 8 * r);
+        __syncthreads();
+        FC_STAMP(3 + 8 * r);
+        {
+            const fc_f32x4 accv = fc_mma(Xh, Xl, wA, kq, q, i16);
+            const uint4* s0 = reinterpret_cast<const uint4*>(a.w0[rn]) + wfrag;   // the next block's fragments (the last block re-reads its own)
+#pragma unroll
+            for (int s = 0; s < 4; s++) wA[s] = s0[s * 64];
+            if (kq > 0) red[((kq - 1) * 4 + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
+            __syncthreads();
+            if (st_wave) {
+                float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
+#pragma unroll
+                for (int t = 1; t < 4; t++) {
+                    const float4 p = red[((t - 1) * 4 + cg) * 64 + lane];
+                    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+                }
+                const float h[4] = {silu1(acc[0] + bias0.x), silu1(acc[1] + bias0.y), silu1(acc[2] + bias0.z), silu1(acc[3] + bias0.w)};
+                if (s_ok) fc_publish(rs, BUF1 + pub_off, base + 2 * r + 1, h);
+            }
+            FC_STAMP(4 + 8 * r);
+        }
+        // ---------------- mlp2: rows = h, gated residual epilogue ----------------
+        float4 bias2 = make_float4(0.f, 0.f, 0.f, 0.f), gate = bias2;
+        if (st_wave) {   // (requested in front of the sweep: they land while it waits)
+            bias2 = *reinterpret_cast<const float4*>(a.b2[r] + scol);
+            gate = *reinterpret_cast<const float4*>(a.ada + srow * a.ldmod + (int64_t)(r * 3 + 2) * FC_C + scol);
+        }
+        if (row_ok) {
+            float4 xr[2];
+            if (!fc_sweep(rs, BUF1 + sweep_off, lane, base + 2 * r + 1, xr)) fault = 1;
+            FC_STAMP(5 + 8 * r);
+            fc_stage(Xh, Xl, wave, lane, xr);
+        }
+        FC_STAMP(6 + 8 * r);
+        __syncthreads();
+        FC_STAMP(7 + 8 * r);
+        {
+            const fc_f32x4 accv = fc_mma(Xh, Xl, wB, kq, q, i16);
+            const uint4* s2 = reinterpret_cast<const uint4*>(a.w2[rn]) + wfrag;
+#pragma unroll
+            for (int s = 0; s < 4; s++) wB[s] = s2[s * 64];
+            if (kq > 0) red[((kq - 1) * 4 + cg) * 64 + lane] = make_float4(accv[0], accv[1], accv[2], accv[3]);
+            __syncthreads();
+            if (st_wave) {
+                float acc[4] = {accv[0], accv[1], accv[2], accv[3]};
+#pragma unroll
+                for (int t = 1; t < 4; t++) {
+                    const float4 p = red[((t - 1) * 4 + cg) * 64 + lane];
+                    acc[0] += p.x; acc[1] += p.y; acc[2] += p.z; acc[3] += p.w;
+                }
+                res.x = res.x + gate.x * (acc[0] + bias2.x);
+                res.y = res.y + gate.y * (acc[1] + bias2.y);
+                res.z = res.z + gate.z * (acc[2] + bias2.z);
+                res.w = res.w + gate.w * (acc[3] + bias2.w);
+                if (s_ok) {
+                    if (r + 1 < a.depth) {
+                        const float v[4] = {res.x, res.y, res.z, res.w};
+                        fc_publish(rs, pub_off, base + 2 * r + 2, v);
+                    } else *reinterpret_cast<float4*>(a.fx_out + srow * FC_C + scol) = res;
+                }
+            }
+            FC_STAMP(8 + 8 * r);
+        }
+    }
+    if (fault && lane == 0) atomicOr(a.sync - tile * 32 + FC_FAULT_WORD, 1u);
+    if (cb == 0 && tid == 0) __hip_atomic_store(sync, base + 2u * (unsigned)a.depth, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    FC_STAMP(63);
+#undef FC_STAMP
+}
+
+bool flow_cluster_supported(const FlowClusterArgs& a, int C) {
+    if (C != FC_C || a.rows <= 0 || a.rows > 64 || a.depth <= 0 || a.depth > FC_MAX_DEPTH || a.ldmod % 4 != 0 || !a.xbuf || !a.sync) return false;
+    if (!aligned16(a.fx_in) || !aligned16(a.fx_out) || !aligned16(a.ada)) return false;
+    for (int r = 0; r < a.depth; r++)
+        if (!a.w0[r] || !a.w2[r] || !a.b0[r] || !a.b2[r] || !a.ln_w[r] || !a.ln_b[r] || !aligned16(a.b0[r]) || !aligned16(a.b2[r]) || !aligned16(a.ln_w[r]) || !aligned16(a.ln_b[r])) return false;
+    return true;
+}
+
+void launch_flow_cluster(const FlowClusterArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {
+    note_launch("k_flow_cluster");
+    const dim3 grid(8 * ((a.rows + 15) / 16));
+    if (a.stamps) hipLaunchKernelGGL(k_flow_cluster<true>, grid, dim3(1024), 0, stream, a);
+    else if (ev0) hipExtLaunchKernelGGL(k_flow_cluster<false>, grid, dim3(1024), 0, stream, ev0, ev1, 0, a);
+    else hipLaunchKernelGGL(k_flow_cluster<false>, grid, dim3(1024), 0, stream, a);
+}
+
+}  // namespace ptts

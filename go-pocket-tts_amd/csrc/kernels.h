@@ -267,6 +267,26 @@ void launch_mimi_rowlin(const RowLinArgs& a, hipStream_t stream);
 bool mimi_ffn_supported(const FfnArgs& a);
 void launch_mimi_ffn(const FfnArgs& a, hipStream_t stream);
 
+// The residual blocks of the flow net (flow_net.go:116-172: `depth` x [adaLN-modulated LayerNorm -> linear + SiLU -> linear, gated, + residual], all C x C) as ONE
+// launch (flow_cluster.hip): 8 workgroups per 16-row tile, each owning 64 output columns of every linear; the rows go round between the eight through tagged
+// 8-byte granules.  Weights: the step kernel's fragment-ordered bf16 copies (Lin::wt).
+constexpr int FC_MAX_DEPTH = 8;
+struct FlowClusterArgs {
+    const float* fx_in = nullptr; float* fx_out = nullptr;   // [rows][C] the residual stream in / out (may be the same buffer)
+    const float* ada = nullptr; int64_t ldmod = 0;           // adaLN rows [rows][ldmod]: block r at 3 r C: shift | scale | gate
+    int rows = 0, depth = 0;
+    float eps[FC_MAX_DEPTH] = {};
+    const float* ln_w[FC_MAX_DEPTH] = {}; const float* ln_b[FC_MAX_DEPTH] = {};
+    const void* w0[FC_MAX_DEPTH] = {}; const float* b0[FC_MAX_DEPTH] = {};
+    const void* w2[FC_MAX_DEPTH] = {}; const float* b2[FC_MAX_DEPTH] = {};
+    unsigned long long* xbuf = nullptr;   // granules {value, tag}: [tile][2][16][C]
+    unsigned long long* stamps = nullptr; // measurement only (null in the product): [workgroup][64] timestamps
+    unsigned* sync = nullptr;             // [tile] the tag base of the tile's next launch, 32 words apart; word 32 * 8: fault flags
+};
+constexpr size_t kFlowClusterXbufBytes = (size_t)4 * 2 * 16 * 512 * 8, kFlowClusterSyncBytes = (size_t)(32 * 8 + 32) * 4;
+bool flow_cluster_supported(const FlowClusterArgs& a, int C);
+void launch_flow_cluster(const FlowClusterArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+
 // AR-step bookkeeping (runtime_native_safetensors.go:176-192 per slot, on device)
 struct StepState {
     int32_t* kv_len;        // [B] keys in the cache (== flowTransformerLayerState.offset)

@@ -90,6 +90,20 @@ Model::~Model() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
+// The decoder's stream.  (experiment: PTTS_DECODE_CUS = n confines it to n of the CUs, dealt evenly over the XCDs, so that the AR step's
+// microsecond launches always find CUs that no millisecond-long decoder block holds)
+static void create_decoder_stream(hipStream_t* s, int prio) {
+    const char* v = getenv("PTTS_DECODE_CUS");
+    const int n = v ? atoi(v) : 0;
+    if (n > 0 && n < 256) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < n; i++) mask[i >> 5] |= 1u << (i & 31);
+        PTTS_HIP(hipExtStreamCreateWithCUMask(s, 8, mask));
+        return;
+    }
+    PTTS_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio));
+}
+
 Model* model_open(Plan* plan, void* device_arena, int fill) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -106,7 +120,7 @@ Model* model_open(Plan* plan, void* device_arena, int fill) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         PTTS_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi));
-        PTTS_HIP(hipStreamCreateWithPriority(&m->stream2, hipStreamNonBlocking, lo));
+        create_decoder_stream(&m->stream2, lo);
     }
     if (device_arena) {
         m->arena = reinterpret_cast<uint8_t*>(device_arena);
@@ -138,7 +152,7 @@ Model* model_share(Model& base) {
     int lo = 0, hi = 0;
     PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     PTTS_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi));
-    PTTS_HIP(hipStreamCreateWithPriority(&m->stream2, hipStreamNonBlocking, lo));
+    create_decoder_stream(&m->stream2, lo);
     m->arena = base.arena;
     m->own_arena = false;
     return m.release();
@@ -183,6 +197,21 @@ const float* Model::tcomb_for(int n) {
 // Batch
 // ------------------------------------------------------------------------------------------------
 Batch::~Batch() {
+    if (fc_stamps.p) {   // (PTTS_FC_STAMPS=<file>: the timestamps of the batch's LAST k_flow_cluster launch, one line per workgroup)
+        std::vector<unsigned long long> h(64 * 64);
+        if (const char* path = getenv("PTTS_FC_STAMPS"))
+            if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), fc_stamps.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+                if (FILE* f = fopen(path, "a")) {
+                    for (int blk = 0; blk < 64; blk++) {
+                        if (!h[(size_t)blk * 64]) continue;
+                        fprintf(f, "wg %d:", blk);
+                        for (int i = 0; i < 64; i++) fprintf(f, " %llu", h[(size_t)blk * 64 + i]);
+                        fprintf(f, "\n");
+                    }
+                    fprintf(f, "\n");
+                    fclose(f);
+                }
+    }
     for (auto& set : graphs) for (auto& row : set) for (hipGraphExec_t g : row) if (g) (void)hipGraphExecDestroy(g);
     if (n_active_pinned) (void)hipHostFree(n_active_pinned);
     if (rows_pinned) (void)hipHostFree(rows_pinned);
@@ -241,7 +270,24 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
         b->fin_dev.ensure(sizeof sf2);
         h2d(b->fin_dev.p, sf2, sizeof sf2, m.stream);
     }
-    PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(1 + 2 * B), hipHostMallocDefault));
+    {   // flow_cluster.hip: bf16 step copies of every residual block's linears, the width it is built for
+        const char* sw = getenv("PTTS_FLOW_CLUSTER");   // A/B switch, read per batch: 0 = the 2 x depth launches (tests compare the two forms bit for bit)
+        const bool off = sw && sw[0] == '0';
+        bool ok = !off && d.flow_dim == 512 && d.flow_depth > 0 && d.flow_depth <= FC_MAX_DEPTH && n_slots <= 64;
+        for (int r = 0; ok && r < d.flow_depth; r++) {
+            const auto& rb = d.rb[r];
+            for (const Lin* l : {&rb.mlp0, &rb.mlp2}) ok = ok && l->in == 512 && l->out == 512 && l->bf16 && !l->wt_i8 && l->wt != NONE && l->b != NONE;
+            ok = ok && rb.ln.w != NONE && rb.ln.b != NONE && rb.ln.d == 512;
+        }
+        b->fc_ok = ok;
+        if (ok) {
+            b->fc_xbuf.ensure(kFlowClusterXbufBytes); b->fc_sync.ensure(kFlowClusterSyncBytes);
+            PTTS_HIP(hipMemsetAsync(b->fc_xbuf.p, 0, kFlowClusterXbufBytes, m.stream));
+            PTTS_HIP(hipMemsetAsync(b->fc_sync.p, 0, kFlowClusterSyncBytes, m.stream));
+            if (getenv("PTTS_FC_STAMPS")) { b->fc_stamps.ensure(64 * 64 * 8); PTTS_HIP(hipMemsetAsync(b->fc_stamps.p, 0, 64 * 64 * 8, m.stream)); }
+        }
+    }
+    PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(2 + 2 * B), hipHostMallocDefault));
     PTTS_HIP(hipHostMalloc((void**)&b->rows_pinned, sizeof(PcmRow) * std::max<size_t>((size_t)B, 1), hipHostMallocDefault));
     batch_reset(*b);
     return b.release();
@@ -602,6 +648,17 @@ static bool open_linears(Batch& b, StepOpenLinears& lin) {
     return true;
 }
 
+// a hand-off inside k_flow_cluster gave up (flow_cluster.hip: bounded sweeps): the frames of this call are not to be trusted.  The exchange state is
+// cleared so that the next call starts clean, and the call fails.
+void flow_cluster_fault(Batch& b) {
+    hipStream_t s = b.m->stream;
+    (void)hipStreamSynchronize(s);
+    (void)hipMemsetAsync(b.fc_xbuf.p, 0, kFlowClusterXbufBytes, s);
+    (void)hipMemsetAsync(b.fc_sync.p, 0, kFlowClusterSyncBytes, s);
+    (void)hipStreamSynchronize(s);
+    throw Error(PTTS_ENODEVICE, "ptts-hip: the flow net's in-launch hand-off timed out (k_flow_cluster); the batch's frames were discarded");
+}
+
 void step_open(Batch& b) {
     Model& m = *b.m;
     const Desc& d = m.d;
@@ -731,7 +788,33 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
         }
         step_gemm(m, mk(m, sy, flat(C), d.ada_all, ada, flat(NA), B));
         if (i > 0 || !opened) step_gemm(m, mk(m, cur, flat(d.ldim), d.input_proj, fx, flat(C), B));
-        for (int r = 0; r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
+        bool clustered = false;
+        if (b.fc_ok) {   // all residual blocks in one launch (flow_cluster.hip)
+            FlowClusterArgs fa;
+            fa.fx_in = fx; fa.fx_out = fx; fa.ada = ada; fa.ldmod = NA; fa.rows = B; fa.depth = d.flow_depth;
+            for (int r = 0; r < d.flow_depth; r++) {
+                const auto& rb = d.rb[r];
+                fa.eps[r] = rb.ln.eps; fa.ln_w[r] = m.at<float>(rb.ln.w); fa.ln_b[r] = m.at<float>(rb.ln.b);
+                fa.w0[r] = m.arena + rb.mlp0.wt; fa.b0[r] = m.at<float>(rb.mlp0.b);
+                fa.w2[r] = m.arena + rb.mlp2.wt; fa.b2[r] = m.at<float>(rb.mlp2.b);
+            }
+            fa.xbuf = b.fc_xbuf.as<unsigned long long>(); fa.sync = b.fc_sync.as<unsigned>();
+            if (b.fc_stamps.p) fa.stamps = b.fc_stamps.as<unsigned long long>();
+            if (flow_cluster_supported(fa, C)) {
+                Prof& p = m.prof;
+                hipEvent_t e0 = nullptr, e1 = nullptr;
+                if (p.on) {
+                    while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
+                    e0 = p.ev[p.used]; e1 = p.ev[p.used + 1];
+                    p.used += 2; p.launches++;
+                    const double wb = (double)d.flow_depth * 2 * C * C * 2;
+                    p.bytes += wb + (double)B * C * 4 * (2 + 4 * d.flow_depth); p.wbytes += wb;   // weights; rows in / out and the exchanged rows (granules: 8 bytes a value, written and read once per workgroup)
+                }
+                launch_flow_cluster(fa, s, e0, e1);
+                clustered = true;
+            }
+        }
+        for (int r = 0; !clustered && r < d.flow_depth; r++) {  // flowResBlock.Forward flow_net.go:116-172 (chunks: shift, scale, gate)
             const auto& rb = d.rb[r];
             FusedIn in;
             in.norm = &rb.ln; in.eps = rb.ln.eps;
@@ -1463,7 +1546,10 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     mark("ar loop");
     // n_frames and eos_step sit side by side in the state block: one copy into page-locked memory, one wait
     PTTS_HIP(hipMemcpyAsync(b.n_active_pinned + 1, b.st.n_frames, (size_t)2 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    b.n_active_pinned[1 + 2 * B] = 0;
+    if (b.fc_ok) PTTS_HIP(hipMemcpyAsync(b.n_active_pinned + 1 + 2 * B, b.fc_fault(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
     PTTS_HIP(hipStreamSynchronize(s));
+    if (b.n_active_pinned[1 + 2 * B]) flow_cluster_fault(b);
     const std::vector<int32_t> nf(b.n_active_pinned + 1, b.n_active_pinned + 1 + B), es(b.n_active_pinned + 1 + B, b.n_active_pinned + 1 + 2 * B);
     int Tmax = 0;
     std::vector<char> overlong((size_t)B, 0);   // utterances that ran past the decoder's reach: failed one by one, like the reference's one GenerateAudio call

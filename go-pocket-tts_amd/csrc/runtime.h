@@ -114,6 +114,10 @@ struct Batch {
     // a chained launch runs several blocks per row tile, so what it writes for the next step (fx, x0) must not be what its other blocks still read:
     // fx / cur alternate with fx2 / cur2 from one chained step to the next (par: which pair the coming step reads; 0 after every k_step_begin)
     DevBuf fx2, cur2;
+    // the flow net's residual blocks as one launch (flow_cluster.hip): granule buffers and the tag / fault words; fc_ok: the model's shapes take it
+    DevBuf fc_xbuf, fc_sync, fc_stamps;   // (fc_stamps: PTTS_FC_STAMPS measurement runs only)
+    bool fc_ok = false;
+    unsigned* fc_fault() const { return fc_sync.as<unsigned>() + 32 * 8; }
     int par = 0;
     float* fx_now() const { return (par ? fx2 : fx).as<float>(); }
     float* cur_now() const { return (par ? cur2 : cur).as<float>(); }
@@ -187,7 +191,8 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 // whether it did (false: the caller launches k_step_finish)
 // chain (with fuse_finish): the last launch also opens the next step (sets b.opened); the frame then lives in the latents only, b.cur holds the next x0
 bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = false, bool chain = false);
-void step_open(Batch& b);                                       // first launch of a generate step (input, noise, the two 32-wide linears)
+void step_open(Batch& b);
+void flow_cluster_fault(Batch& b);   // throws (after clearing the exchange state)                                       // first launch of a generate step (input, noise, the two 32-wide linears)
 // xformer_out (optional, staged parity checks): the decoder transformer's output rows [B][T * up_stride][mimi_dim]
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev, float* xformer_out = nullptr);
 // pieces of the generate loop that the continuous batch (continuous.cpp) reuses
