@@ -14,8 +14,11 @@
 // Nothing in the loop waits for the GPU to run dry: the counters of group g are read (asynchronously, into page-locked memory) while
 // group g + 1 is already queued, admissions and decodes are queued behind the group in flight, per-slot device state is written slot
 // by slot by one small kernel (never as whole arrays: the other slots are live), and small uploads go through two page-locked arenas
-// used in turn.  Prefills and decodes interrupt / compete with the step chain, so both are batched: newcomers are admitted every
-// few groups (or at once into an empty engine), finished utterances are decoded a handful at a time.
+// used in turn.  Prefills and decodes compete with the step chain for the chip.  What round 4's group trace (PTTS_CONT_TRACE, tools/cont_trace_summary.py)
+// showed and changed: newcomers are admitted every turn and start stepping with the very next group (the step STREAM waits for their prefill, not the
+// host); finished utterances are decoded sixteen at a time, in sub-groups of like length (a decode pads to its longest member), on a stream of the
+// engine's own that is confined to half of the CUs; and the decoder's input is gathered on the step stream, which no longer waits for anything the
+// decoder does.
 // The engine has a fixed geometry (slots, KV capacity, step budget); requests that do not fit it or need per-step host work (step /
 // PCM callbacks, lsd_steps > 1) are left to the batch-at-a-time path.
 #include <algorithm>
@@ -27,7 +30,11 @@
 namespace ptts {
 
 namespace {
-int tune(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }   // (tuning sweep: tools/gpu_serve_sweep.sh)
+// The pacing below was swept on one MI355X at 128 clients, utterances of 2-12 s (profiles/r4_serve_sweep.txt; tools/gpu_cont_trace.sh):
+constexpr int kDecoderCUs = 128;      // CUs open to the decoder's stream (of 256): see cont_create
+constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
+constexpr int kDecodeMaxAge = 8;      // ... or the oldest has waited this many groups of steps (a caller waiting for audio is a caller not sending its next request)
+constexpr int kBandFrames = 16, kBandPercent = 16;   // a decode pads everything to its longest member: members within max(16 frames, 16 %) of it
 constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
 }
 
@@ -65,7 +72,8 @@ struct ContEngine {
     // newcomers whose voice ingestion and prefill are running on the I/O stream; they start stepping once that is done
     struct Joining { hipEvent_t ready = nullptr; std::vector<int> slots; int ring = 0; uint64_t seq = 0; };
     std::deque<Joining> joining;
-    hipStream_t io = nullptr;
+    hipStream_t io = nullptr;             // prefills of newcomers: the model's second stream
+    hipStream_t dec = nullptr;            // the decoder's stream of this engine: confined to half of the CUs (cont_create)
     DevBuf adm_dev[4];
     int adm_turn = 0;
     std::vector<hipEvent_t> free_events;
@@ -98,7 +106,8 @@ struct ContEngine {
     ~ContEngine() {
         (void)hipStreamSynchronize(m.stream);
         (void)hipStreamSynchronize(m.stream2);
-        if (io) { (void)hipStreamSynchronize(io); (void)hipStreamDestroy(io); }
+        if (io) (void)hipStreamSynchronize(io);   // (the model's second stream: not ours to destroy)
+        if (dec) { (void)hipStreamSynchronize(dec); (void)hipStreamDestroy(dec); }
         if (trace_path && !trace.empty()) {
             if (FILE* f = fopen(trace_path, "a")) {
                 fprintf(f, "# gap_us dur_us n_gen steps admitted decodes_started decoding joining\n");
@@ -161,7 +170,25 @@ ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
     }
     for (int i = 0; i < 2; i++) PTTS_HIP(hipEventCreateWithFlags(&e->arena_free[i], hipEventDisableTiming));
     b.slot_local = true;
-    PTTS_HIP(hipStreamCreateWithFlags(&e->io, hipStreamNonBlocking));
+    // Three streams and no more: the step chain's (the model's first), the prefills' (the model's second: idle while the engine holds the model) and the
+    // decoder's below.  With a stream of its own for the prefills as well (round 3's layout plus the decoder's stream: four user streams) every step ran as
+    // if confined to the decoder's CUs and queued behind its kernels -- 6.1 k x real time instead of 10.9 k, "alone" groups 410 us a step instead of 290
+    // (profiles/r4_serve_sweep.txt, "decoder stream modes"; GPU_MAX_HW_QUEUES = 8 did not change it: how this runtime maps streams onto hardware queues
+    // once a CU-masked one exists is not established, so the engine stays at the stream count that measures well).
+    e->io = m.stream2;
+    {
+        // Decodes run BESIDE the step chain here (in a one-shot batch they follow it), and a decoder block holds its CU for a fraction of a millisecond
+        // while a step launch lasts microseconds: with the whole chip open to the decoder every step launch of that time queued behind decoder blocks
+        // (steps 6x slower for the length of a decode, PTTS_CONT_TRACE).  Confined to half of the CUs (CU-mask bits are dealt round the XCDs: 16 of each
+        // XCD's 32) the decoder takes twice as long and the steps beside it 1.4x instead of 6x: +5 % throughput at 128 clients (96 / 160 / 192 CUs:
+        // +3 / +4 / +0 %; 64: the decoder falls behind), profiles/r4_serve_sweep.txt.
+        const int n_cu = kDecoderCUs;
+        if (n_cu > 0 && n_cu < 256) {
+            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < n_cu; i++) mask[i >> 5] |= 1u << (i & 31);
+            PTTS_HIP(hipExtStreamCreateWithCUMask(&e->dec, 8, mask));
+        } else PTTS_HIP(hipStreamCreateWithFlags(&e->dec, hipStreamNonBlocking));
+    }
     b.io_stream = e->io;
     for (DevBuf& db : e->adm_dev) db.ensure((size_t)slots * sizeof(SlotAdmit));
     e->stage.ensure((size_t)2 * slots * b.max_steps * m.d.ldim * sizeof(float));
@@ -324,8 +351,7 @@ static void activate_ready(ContEngine& e, bool wait) {
             if (q == hipErrorNotReady) {
                 // the prefill is still running beside the group in flight: the step STREAM waits for it (in front of the next group) rather than the host
                 // looking again a group later -- a newcomer idles one group less, at the price of a short stall of everyone when the prefill is the slower
-                static const int eager = tune("PTTS_CONT_EAGER", 0);
-                if (eager == 0 || (eager == 1 && j.seq == e.seq)) return;
+                // (waiting a group instead: occupancy 54.5 -> 58 of 64 slots with it, +3..5 % throughput)
                 PTTS_HIP(hipStreamWaitEvent(e.m.stream, j.ready, 0));
             } else if (q != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipEventQuery failed: %s", hipGetErrorString(q)));
         }
@@ -346,7 +372,7 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
     const Desc& d = m.d;
     const int ld = d.ldim;
     const int64_t spf = d.samples_per_frame;
-    hipStream_t s = m.stream, s2 = m.stream2;
+    hipStream_t s = m.stream, s2 = e.dec;
     e.tr_decodes += (int)fin.size();
     std::sort(fin.begin(), fin.end(), [](const ContEngine::Staged& x, const ContEngine::Staged& y) { return x.nf > y.nf; });   // like lengths together: less padding
     // sub-groups whose decode fits the workspace; their frames are gathered FIRST, all of them, and on the AR stream itself: the staging rows are that
@@ -363,8 +389,8 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
             const int t2 = std::max(T, std::max(1, fin[end].nf));
             if (end > at && (int64_t)t2 * (int64_t)(end - at + 1) > kFramesPerDecode) break;
             // (sorted by length: everything in the sub-group is padded to its first; a member much shorter than that starts the next one)
-            static const int band = tune("PTTS_CONT_BAND", 0);
-            if (band > 0 && end > at && fin[at].nf - fin[end].nf > std::max(band, fin[at].nf * band / 100)) break;
+            // (without this rule a third of the decoder's frames were padding: 74 964 decoded for 56 948 real ones in the benchmark run; with it 60 757)
+            if (end > at && fin[at].nf - fin[end].nf > std::max(kBandFrames, fin[at].nf * kBandPercent / 100)) break;
             T = t2; end++;
         }
         subs.push_back(Sub{at, end, T, total});
@@ -539,8 +565,7 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
         if (!e.staged.empty()) {
             uint64_t oldest = e.seq;
             for (const ContEngine::Staged& f : e.staged) oldest = std::min(oldest, f.seq);
-            static const int dmin = tune("PTTS_CONT_DECODE_MIN", 0), dage = tune("PTTS_CONT_DECODE_AGE", 8);
-            if ((int)e.staged.size() >= (dmin > 0 ? dmin : std::max(4, B / 3)) || (int)(e.seq - oldest) >= dage || e.n_gen == 0 || drain) start_decode(e, e.staged);
+            if ((int)e.staged.size() >= std::min(kDecodeMin, std::max(4, B / 3)) || (int)(e.seq - oldest) >= kDecodeMaxAge || e.n_gen == 0 || drain) start_decode(e, e.staged);
         }
         while (!e.decoding.empty()) {
             ContEngine::Pending& p = e.decoding.front();
@@ -559,20 +584,17 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
     e.unlock_if_idle();
 }
 
-// newcomers are admitted at once into an engine with nothing generating, otherwise every fourth group (a prefill interrupts the step
-// chain of everyone else for ~0.5 ms however few rows it has), or as soon as a quarter of the slots can be filled in one go
+// newcomers are admitted whenever a slot is free: every turn of the engine (round 3 admitted every fourth group to spare the step chain the prefills; since
+// small prefills run as chunks of the step kernel -- kernels.hip launch_gemm -- a prefill costs the chain ~7 % while it runs, an idle slot costs 1.6 % each)
 bool cont_admit_now(const ContEngine& e, int waiting) {
-    if (waiting <= 0 || e.free_slots() == 0) return false;
-    if (e.n_gen == 0) return true;
-    static const int every = tune("PTTS_CONT_ADMIT_EVERY", 4), quarter = tune("PTTS_CONT_ADMIT_MIN", 0);
-    if ((int)(e.seq - e.last_admit_seq) >= every) return true;
-    return std::min(waiting, e.free_slots()) >= (quarter > 0 ? quarter : std::max(1, e.B / 4));
+    return waiting > 0 && e.free_slots() > 0;
 }
 
 // every request in flight is answered with `code` (the engine is about to be torn down after an error)
 void cont_abort(ContEngine& e, int code, std::vector<void*>& done) {
     (void)hipStreamSynchronize(e.m.stream);
     (void)hipStreamSynchronize(e.m.stream2);
+    if (e.dec) (void)hipStreamSynchronize(e.dec);
     if (e.io) (void)hipStreamSynchronize(e.io);
     for (auto& j : e.joining) if (j.ready) e.free_events.push_back(j.ready);
     e.joining.clear();

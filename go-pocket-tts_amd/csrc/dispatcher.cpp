@@ -51,7 +51,7 @@ struct Dispatcher {
     std::vector<std::thread> workers;
     // continuous batching (continuous.cpp): one long-lived batch per model; free slots are refilled between groups of AR steps
     bool continuous = false;
-    int cont_kv_cap = 512, cont_max_steps = 256, cont_group = 5;
+    int cont_kv_cap = 512, cont_max_steps = 256, cont_group = 3;
     // statistics
     int64_t n_requests = 0, n_batches = 0, n_cancelled_waiting = 0, max_depth = 0;
     double sum_wait_us = 0.0, sum_exec_us = 0.0;

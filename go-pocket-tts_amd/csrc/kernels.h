@@ -279,11 +279,12 @@ struct FlowClusterArgs {
     const float* ln_w[FC_MAX_DEPTH] = {}; const float* ln_b[FC_MAX_DEPTH] = {};
     const void* w0[FC_MAX_DEPTH] = {}; const float* b0[FC_MAX_DEPTH] = {};
     const void* w2[FC_MAX_DEPTH] = {}; const float* b2[FC_MAX_DEPTH] = {};
-    unsigned long long* xbuf = nullptr;   // granules {value, tag}: [tile][2][16][C]
+    unsigned long long* xbuf = nullptr;   // granules {value, tag}: [tile of 12 rows][2][16][C]
     unsigned long long* stamps = nullptr; // measurement only (null in the product): [workgroup][64] timestamps
     unsigned* sync = nullptr;             // [tile] the tag base of the tile's next launch, 32 words apart; word 32 * 8: fault flags
 };
-constexpr size_t kFlowClusterXbufBytes = (size_t)4 * 2 * 16 * 512 * 8, kFlowClusterSyncBytes = (size_t)(32 * 8 + 32) * 4;
+constexpr size_t kFlowClusterXbufBytes = (size_t)6 * 2 * 16 * 512 * 8,   // six 12-row tiles
+                  kFlowClusterSyncBytes = (size_t)(32 * 8 + 32) * 4;
 bool flow_cluster_supported(const FlowClusterArgs& a, int C);
 void launch_flow_cluster(const FlowClusterArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 

@@ -90,20 +90,6 @@ Model::~Model() {
     if (stream) (void)hipStreamDestroy(stream);
 }
 
-// The decoder's stream.  (experiment: PTTS_DECODE_CUS = n confines it to n of the CUs, dealt evenly over the XCDs, so that the AR step's
-// microsecond launches always find CUs that no millisecond-long decoder block holds)
-static void create_decoder_stream(hipStream_t* s, int prio) {
-    const char* v = getenv("PTTS_DECODE_CUS");
-    const int n = v ? atoi(v) : 0;
-    if (n > 0 && n < 256) {
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < n; i++) mask[i >> 5] |= 1u << (i & 31);
-        PTTS_HIP(hipExtStreamCreateWithCUMask(s, 8, mask));
-        return;
-    }
-    PTTS_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, prio));
-}
-
 Model* model_open(Plan* plan, void* device_arena, int fill) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -120,7 +106,7 @@ Model* model_open(Plan* plan, void* device_arena, int fill) {
         int lo = 0, hi = 0;   // numerically lower = higher priority
         PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         PTTS_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi));
-        create_decoder_stream(&m->stream2, lo);
+        PTTS_HIP(hipStreamCreateWithPriority(&m->stream2, hipStreamNonBlocking, lo));
     }
     if (device_arena) {
         m->arena = reinterpret_cast<uint8_t*>(device_arena);
@@ -152,7 +138,7 @@ Model* model_share(Model& base) {
     int lo = 0, hi = 0;
     PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
     PTTS_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi));
-    create_decoder_stream(&m->stream2, lo);
+    PTTS_HIP(hipStreamCreateWithPriority(&m->stream2, hipStreamNonBlocking, lo));
     m->arena = base.arena;
     m->own_arena = false;
     return m.release();

@@ -245,7 +245,7 @@ typedef struct ptts_dispatch_opts {
                            * batch-at-a-time while the engine is empty.  0: batch-at-a-time for everything */
     int32_t cont_kv_capacity;      /* keys per slot (voice prefix + prompt + steps), <= 0: 512 (the reach of the one-burst step attention with a bf16 cache) */
     int32_t cont_max_steps;        /* step budget per utterance, <= 0: 256 (EstimateMaxFrames of a 50-token chunk is 234) */
-    int32_t cont_steps_per_group;  /* AR steps between two looks at the slots, <= 0: 5 */
+    int32_t cont_steps_per_group;  /* AR steps between two looks at the slots, <= 0: 3 */
     int32_t reserved[1];
 } ptts_dispatch_opts;
 typedef struct ptts_dispatch_stats {
