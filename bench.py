@@ -296,6 +296,9 @@ def roofline_pass(pkg, model, wl, prompts, voice, traffic=None):
         r["frac_note"] = "achieved / frac use the longer of the two mean launch durations (in-process events, rocprofv3 kernel trace of the same workload)"
     elif tr:
         r["avg_launch_us_rocprof_note"] = tr[2]
+    if tr and len(tr) > 3 and tr[3]:
+        r["flow_cluster"] = {"avg_launch_us_rocprof": round(tr[3][0], 3), "launches_rocprof": tr[3][1],
+                             "note": "k_flow_cluster: the flow net's 12 residual-block linears (6.3 MB of the step's 170.5 MB of weights) as one launch per AR step; not a launch of the dominant kernel, not in avg_launch_us"}
     if traffic and traffic.get(prof["kernel"]):
         t = traffic[prof["kernel"]]
         r["traffic"] = t.get("bytes_per_launch")
@@ -362,12 +365,15 @@ def trace_pass(steps, kernel="k_skinny"):
         files = glob.glob(os.path.join(out_dir, "**", "*kernel_trace.csv"), recursive=True)
         if p.returncode != 0 or not files:
             return None, 0, f"rocprofv3 --kernel-trace failed (rc {p.returncode}): {(p.stderr or '')[-300:]}"
-        tot, n = 0, 0
+        tot, n, fc_tot, fc_n = 0, 0, 0, 0
         for r in csv.DictReader(open(files[0])):
             if kernel in r["Kernel_Name"]:
                 tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
                 n += 1
-        return (tot / n / 1e3 if n else None), n, None
+            elif "k_flow_cluster" in r["Kernel_Name"]:   # the flow net's residual blocks: one launch per AR step beside the step linears
+                fc_tot += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                fc_n += 1
+        return (tot / n / 1e3 if n else None), n, None, ((fc_tot / fc_n / 1e3, fc_n) if fc_n else None)
     finally:
         shutil.rmtree(out_dir, ignore_errors=True)
 

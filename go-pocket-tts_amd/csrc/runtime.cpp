@@ -787,16 +787,8 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
             fa.xbuf = b.fc_xbuf.as<unsigned long long>(); fa.sync = b.fc_sync.as<unsigned>();
             if (b.fc_stamps.p) fa.stamps = b.fc_stamps.as<unsigned long long>();
             if (flow_cluster_supported(fa, C)) {
-                Prof& p = m.prof;
-                hipEvent_t e0 = nullptr, e1 = nullptr;
-                if (p.on) {
-                    while (p.ev.size() < p.used + 2) { hipEvent_t e; PTTS_HIP(hipEventCreate(&e)); p.ev.push_back(e); }
-                    e0 = p.ev[p.used]; e1 = p.ev[p.used + 1];
-                    p.used += 2; p.launches++;
-                    const double wb = (double)d.flow_depth * 2 * C * C * 2;
-                    p.bytes += wb + (double)B * C * 4 * (2 + 4 * d.flow_depth); p.wbytes += wb;   // weights; rows in / out and the exchanged rows (granules: 8 bytes a value, written and read once per workgroup)
-                }
-                launch_flow_cluster(fa, s, e0, e1);
+                // (not a launch of the step linear: the bench's per-launch events and byte counts -- Prof -- leave it out; bench.py reports it from the kernel trace)
+                launch_flow_cluster(fa, s);
                 clustered = true;
             }
         }

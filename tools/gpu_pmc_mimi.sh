@@ -14,4 +14,4 @@ run sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU
 run lds SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT &&
 run fetch FETCH_SIZE &&
 run write WRITE_SIZE
-for n in sq lds fetch write; do echo "## $n"; grep -A1 "k_gemm5\|k_resblock\|k_gemm_wres\|k_attn_window\|k_layernorm" gpurun_out/${tag}_$n.txt | cut -c1-260 | head -60; done
+for n in sq lds fetch write; do echo "## $n"; grep -A1 "k_gemm5\|k_resblock\|k_gemm_wres\|k_attn_window\|k_layernorm\|k_mimi" gpurun_out/${tag}_$n.txt | cut -c1-260 | head -60; done
