@@ -417,10 +417,8 @@ bool mimi_ffn_supported(const FfnArgs& a) {
 
 void launch_mimi_ffn(const FfnArgs& a, hipStream_t stream) {
     note_launch("k_mimi_ffn");
-    static const int v = [] { const char* e = getenv("PTTS_FFN_V"); return e ? atoi(e) : 0; }();   // measurement
     const dim3 grid((unsigned)((a.M + 63) / 64));
-    if (v == 1) hipLaunchKernelGGL(k_mimi_ffn<1>, grid, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(k_mimi_ffn<0>, grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(k_mimi_ffn<0>, grid, dim3(256), 0, stream, a);   // (<1>: the no-copies ablation of tools/gpu_mimi_ab.sh's record, profiles/r4_mimi_ab.txt; instantiate it here to repeat it)
 }
 
 }  // namespace ptts

@@ -890,8 +890,7 @@ void mimi_layer_qkv(Model& m, int l, const float* x, RowMap xmap, int R, float* 
         ra.y = qkv; ra.ymap = qmap;
         ra.rope_cos = m.at<float>(d.rope_cos); ra.rope_sin = m.at<float>(d.rope_sin); ra.rope_cols = 2 * C; ra.rope_pos0 = pos0; ra.rope_rows_per_seg = rows_per_seg;
         ra.M = R; ra.N = 3 * C; ra.K = C;
-        static const int want = [] { const char* e = getenv("PTTS_QKV_FUSED"); return e ? atoi(e) : 1; }();   // A/B measurement
-        if (want && mimi_rowlin_supported(ra)) { launch_mimi_rowlin(ra, s); return; }
+        if (mimi_rowlin_supported(ra)) { launch_mimi_rowlin(ra, s); return; }
     }
     launch_layernorm(mkln(m, x, xmap, L.n1, n1, C, R), s);
     GemmArgs gq = mk(m, n1, flat(C), L.in_proj, qkv, qmap, R);
@@ -917,8 +916,7 @@ void mimi_layer_ffn(Model& m, int l, float* x, RowMap xmap, int R, float* n1, fl
         fa.img = m.at<uint8_t>(L.ffn_img);
         fa.ls = m.at<float>(L.ls2);
         fa.M = R; fa.D = C; fa.F = F;
-        static const int want = [] { const char* e = getenv("PTTS_FFN_FUSED"); return e ? atoi(e) : 1; }();   // A/B measurement
-        if (want && mimi_ffn_supported(fa)) { launch_mimi_ffn(fa, s); return; }
+        if (mimi_ffn_supported(fa)) { launch_mimi_ffn(fa, s); return; }
     }
     launch_layernorm(mkln(m, x, xmap, L.n2, n1, C, R), s);
     GemmArgs g1 = mk(m, n1, flat(C), L.l1, ffb, flat(F), R);
@@ -1156,10 +1154,6 @@ int resolve_max_steps(const ptts_request& r) {  // runtime_native_safetensors.go
     return ms;
 }
 
-static bool chain_steps() {
-    static const bool on = [] { const char* e = getenv("PTTS_CHAIN_OPEN"); return !e || atoi(e) != 0; }();   // A/B measurement (0: k_step_begin in front of every step)
-    return on;
-}
 
 // the graph of `nsteps` consecutive AR steps whose attention launches cover `ni` load rounds (captured on first use, kept with
 // the batch).  Several steps per graph: the gap between two replays (~8 us of idle GPU) is paid once per graph.
@@ -1192,7 +1186,7 @@ static hipGraphExec_t step_graph(Batch& b, int lsd, int ni, int nsteps) {
         b.opened = false;
         for (int k = 0; k < nsteps; k++) {
             if (!b.opened) step_open(b);
-            if (!step_core(b, lsd, b.opened, true, chain_steps() && k + 1 < nsteps))
+            if (!step_core(b, lsd, b.opened, true, k + 1 < nsteps))
                 launch_step_finish(b.st, b.cur_now(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
         }
         b.opened = false;
@@ -1226,7 +1220,7 @@ void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps) {
     // plain launches: the previous step's last launch normally opened this one (b.opened); whoever changes a slot between two steps
     // (batch_reset, admission of a newcomer, the staged API) clears the flag, and k_step_begin opens the step for every row
     if (!b.opened) step_open(b);
-    if (!step_core(b, lsd, b.opened, true, chain_steps()))   // the bookkeeping rides in the step's last launch (shapes it does not take: k_step_finish)
+    if (!step_core(b, lsd, b.opened, true, true))   // the bookkeeping rides in the step's last launch (shapes it does not take: k_step_finish)
         launch_step_finish(b.st, b.cur_now(), b.eos.as<float>(), ld, b.B, b.latents.as<float>(), ls, m.stream);
 }
 
