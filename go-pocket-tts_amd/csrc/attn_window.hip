@@ -1,5 +1,6 @@
 // attn_window.hip -- sliding-window self-attention of the Mimi decoder transformer (K15; mimi.go:365-441,
 // attention.go:307-484 with context 250: a query at position p sees keys p-249 .. p of its own utterance).
+#include <cstdlib>
 #include <type_traits>
 
 #include "kernels.h"
@@ -187,6 +188,200 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same attention for the decoder's dense case (f32 K / V, a window, every segment the same length) with the key tiles SHARED: a block is four waves =
+// 128 consecutive queries of one (utterance, head), whose windows together span at most 128 + context - 1 keys.  Each 32-key tile of that span is fetched
+// and split into bf16 hi / lo ONCE per block, by all 256 threads, into LDS images laid out as the two products' A operands, and every wave whose window
+// touches the tile multiplies from there.  Per wave and tile the kernel above issues 40 vector-memory instructions (32 of them 4-byte loads for V^T) and 40
+// operand splits for 24 matrix instructions -- its matrix pipe is busy 17 % of the time (profiles/r4_pmc_mimi.txt); here a thread issues 10 loads and 8
+// splits per tile, a wave 16 ds_read_b128.
+//   K image (per half hi / lo): [32 keys][128 B = 64 dims bf16], the 16-byte chunk c (dims 8c .. 8c+7) of key k at position c ^ ((k >> 1) & 7): the
+//     fragment read of step i (lane: key = lane & 31, g = lane >> 5 -> chunk 2i + g) is conflict-free for every 16 lanes.
+//   V^T image (per half): [64 dims][64 B = 32 keys bf16 in the ORDER the score registers hold them: position 16 i + 8 g + 4 b + e = key 16 i + 8 b + 4 g + e],
+//     chunk c = 2i + g of dim d at position c ^ ((d >> 2) & 3).
+// Two buffers: the loads of tile t + 1 are requested before tile t is multiplied, split and written behind it, one barrier per tile.
+// Tiles are aligned to the block's first visible key (not each wave's own): the sums of a row are grouped differently from the kernel above for the first
+// context + 96 positions of an utterance -- rounding-order differences, held by the same tolerances.
+// ------------------------------------------------------------------------------------------------
+constexpr int AW_KB = 32 * 128;   // bytes of one K half image
+constexpr int AW_VB = 64 * 64;    // bytes of one V^T half image
+constexpr int AW_TILE = 2 * AW_KB + 2 * AW_VB;   // 16 KB per tile: K hi | K lo | V^T hi | V^T lo
+
+template <int NW>   // waves = 32-query tiles per block (4: 128 queries, 12 key tiles of which a wave uses 9; 2: 64 queries, 10 of which it uses 9)
+__global__ __launch_bounds__(64 * NW) void k_attn_window_lds(AttnArgs a, int qblocks) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * AW_TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x;
+    const int seg = blockIdx.y / qblocks, qb = blockIdx.y % qblocks;
+    const int seg_rows = a.rows_per_seg;
+    constexpr int QB = 32 * NW, SU = 4 / NW;         // queries per block; staging units per thread
+    const int b0 = qb * QB;                          // the block's first query row of the segment
+    const int r0 = b0 + wave * 32;                   // the wave's
+    const bool wave_on = r0 < seg_rows;              // (a wave without queries still stages tiles and keeps the barriers' count)
+    const int nq = wave_on ? min(32, seg_rows - r0) : 1;
+    const int j = lane & 31, half = lane >> 5;
+    const int my_q = min(j, nq - 1);
+    const int ctx = a.context;
+    const int pb_first = a.pos_base + b0, pb_last = a.pos_base + min(b0 + QB, seg_rows) - 1;   // positions of the block's queries
+    const int p_first = a.pos_base + (wave_on ? r0 : b0), p_last = p_first + nq - 1;
+    const int my_pos = p_first + my_q;
+    const int jb_lo = max(0, pb_first - ctx + 1);    // first key any query of the block sees
+    const int jw_lo = max(0, p_first - ctx + 1);     // ... this wave's
+    const RowMap qm{a.q_ld, a.q_rows_per_batch, a.q_batch_stride}, om{a.out_ld, a.o_rows_per_batch, a.o_batch_stride};
+    const int row = seg * seg_rows + (wave_on ? r0 : b0) + my_q;
+
+    FragW qh[4], ql[4];   // step i: dims 16 i + 8 half .. + 7 of the lane's query, scaled by 1/sqrt(64) (exact)
+    {
+        const float* qp = a.q + row_off(qm, row) + a.q_col0 + h * 64 + half * 8;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const float4 t0 = *reinterpret_cast<const float4*>(qp + 16 * i), t1 = *reinterpret_cast<const float4*>(qp + 16 * i + 4);
+            split2w(t0.x * 0.125f, t0.y * 0.125f, qh[i].u[0], ql[i].u[0]);
+            split2w(t0.z * 0.125f, t0.w * 0.125f, qh[i].u[1], ql[i].u[1]);
+            split2w(t1.x * 0.125f, t1.y * 0.125f, qh[i].u[2], ql[i].u[2]);
+            split2w(t1.z * 0.125f, t1.w * 0.125f, qh[i].u[3], ql[i].u[3]);
+        }
+    }
+    const float* kb = (const float*)a.k + (int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride;
+    const float* vb = (const float*)a.v + (int64_t)seg * a.k_seg_stride + (int64_t)h * a.k_head_stride;
+
+    // ---- staging roles: 256 units over the block's 64 NW threads (unit id = tid + 64 NW u) ----
+    // K: unit -> (key sk = id >> 3, dims 8 (id & 7) .. + 7): two float4, one 16-byte chunk of the image per half
+    // V^T: unit -> (dim sd = id & 63, key group sg = id >> 6 (0..3): positions 8 sg .. 8 sg + 7 of the image row, i.e. chunk sg = 2i + g, keys 16 i + 8 b + 4 g + e)
+    const int rs = (int)a.k_row_stride;             // (a segment's rows fit 32-bit element offsets: host check)
+    float4 sk0[SU], sk1[SU];
+    float sv[SU][8];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int id = tid + 64 * NW * u;
+            const int sk = id >> 3, sc = id & 7, sd = id & 63, sg = id >> 6;
+            const int v_key0 = 16 * (sg >> 1) + 4 * (sg & 1);   // keys v_key0 + e and v_key0 + 8 + e, e = 0..3
+            const int key = min(kt + sk, pb_last);      // (keys past the block's last position are never visible: a valid row is read again)
+            const float* kp = kb + sc * 8 + key * rs;
+            sk0[u] = *reinterpret_cast<const float4*>(kp);
+            sk1[u] = *reinterpret_cast<const float4*>(kp + 4);
+            if (kt + 31 <= pb_last) {                   // (block-uniform) a whole tile: no clamping, one base + constant offsets
+                const float* vp = vb + sd + (kt + v_key0) * rs;
+#pragma unroll
+                for (int e = 0; e < 8; e++) sv[u][e] = vp[((e & 3) + 8 * (e >> 2)) * rs];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; e++) sv[u][e] = vb[sd + min(kt + v_key0 + (e & 3) + 8 * (e >> 2), pb_last) * rs];
+            }
+        }
+    };
+    auto stage_store = [&](unsigned char* buf) {
+#pragma unroll
+        for (int u = 0; u < SU; u++) {
+            const int id = tid + 64 * NW * u;
+            const int sk = id >> 3, sc = id & 7, sd = id & 63, sg = id >> 6;
+            const int k_dst = sk * 128 + ((sc ^ ((sk >> 1) & 7)) << 4);
+            const int v_dst = sd * 64 + ((sg ^ ((sd >> 2) & 3)) << 4);
+            uint4 hq, lq;
+            split2w(sk0[u].x, sk0[u].y, hq.x, lq.x);
+            split2w(sk0[u].z, sk0[u].w, hq.y, lq.y);
+            split2w(sk1[u].x, sk1[u].y, hq.z, lq.z);
+            split2w(sk1[u].z, sk1[u].w, hq.w, lq.w);
+            *reinterpret_cast<uint4*>(buf + k_dst) = hq;
+            *reinterpret_cast<uint4*>(buf + AW_KB + k_dst) = lq;
+            split2w(sv[u][0], sv[u][1], hq.x, lq.x);
+            split2w(sv[u][2], sv[u][3], hq.y, lq.y);
+            split2w(sv[u][4], sv[u][5], hq.z, lq.z);
+            split2w(sv[u][6], sv[u][7], hq.w, lq.w);
+            *reinterpret_cast<uint4*>(buf + 2 * AW_KB + v_dst) = hq;
+            *reinterpret_cast<uint4*>(buf + 2 * AW_KB + AW_VB + v_dst) = lq;
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; r++) { o0[r] = 0.0f; o1[r] = 0.0f; }
+    float m = -INFINITY, l = 0.0f;
+    // fragment addresses of this lane inside a tile buffer
+    const int ka = j * 128, ksw = (j >> 1) & 7;            // K: chunk 2 i + half
+    const int va0 = j * 64, va1 = (j + 32) * 64, vsw0 = (j >> 2) & 3, vsw1 = ((j + 32) >> 2) & 3;   // V^T rows j and 32 + j: chunk 2 i + half
+
+    stage_load(jb_lo);
+    stage_store(lds);
+    __syncthreads();
+    int t = 0;
+    for (int kt = jb_lo; kt <= pb_last; kt += 32, t ^= 1) {
+        const unsigned char* buf = lds + t * AW_TILE;
+        const bool more = kt + 32 <= pb_last;
+        if (more) stage_load(kt + 32);
+        if (wave_on && kt + 31 >= jw_lo && kt <= p_last) {   // the tile holds keys some query of this wave sees (wave-uniform)
+            f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; r++) s[r] = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                FragW kh, kl;
+                kh.q = *reinterpret_cast<const uint4*>(buf + ka + (((2 * i + half) ^ ksw) << 4));
+                kl.q = *reinterpret_cast<const uint4*>(buf + AW_KB + ka + (((2 * i + half) ^ ksw) << 4));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh.v, qh[i].v, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl.v, qh[i].v, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh.v, ql[i].v, s, 0, 0, 0);
+            }
+            float tmax = -INFINITY;
+            if (kt + 31 <= p_first && kt > p_last - ctx) {   // (wave-uniform) every key of the tile is visible to every query of the wave: no mask
+#pragma unroll
+                for (int r = 0; r < 16; r++) tmax = fmaxf(tmax, s[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int key = kt + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const bool ok = key <= my_pos && key > my_pos - ctx;
+                    s[r] = ok ? s[r] : -INFINITY;
+                    tmax = fmaxf(tmax, s[r]);
+                }
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, WAVE));
+            const float m_new = fmaxf(m, tmax);
+            const float m_use = m_new == -INFINITY ? 0.0f : m_new;   // a tile may hold no visible key for this query yet
+            const float alpha = __expf(m - m_use);
+            m = m_new;
+            l *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; r++) { o0[r] *= alpha; o1[r] *= alpha; }
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                s[r] = __expf(s[r] - m_use);
+                l += s[r];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                FragW ph, pl, vh0, vl0, vh1, vl1;
+#pragma unroll
+                for (int e = 0; e < 4; e++) split2w(s[8 * i + 2 * e], s[8 * i + 2 * e + 1], ph.u[e], pl.u[e]);
+                const unsigned char* vt = buf + 2 * AW_KB;
+                vh0.q = *reinterpret_cast<const uint4*>(vt + va0 + (((2 * i + half) ^ vsw0) << 4));
+                vl0.q = *reinterpret_cast<const uint4*>(vt + AW_VB + va0 + (((2 * i + half) ^ vsw0) << 4));
+                vh1.q = *reinterpret_cast<const uint4*>(vt + va1 + (((2 * i + half) ^ vsw1) << 4));
+                vl1.q = *reinterpret_cast<const uint4*>(vt + AW_VB + va1 + (((2 * i + half) ^ vsw1) << 4));
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, ph.v, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0.v, ph.v, o0, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, pl.v, o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, ph.v, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1.v, ph.v, o1, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, pl.v, o1, 0, 0, 0);
+            }
+        }
+        if (more) stage_store(lds + (t ^ 1) * AW_TILE);
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 32, WAVE);
+    if (wave_on && j < nq) {
+        const float inv = 1.0f / l;   // the key at the query's own position is always visible
+        float* op = a.out + row_off(om, row) + h * 64 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            *reinterpret_cast<float4*>(op + 8 * g) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+            *reinterpret_cast<float4*>(op + 32 + 8 * g) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+        }
+    }
+}
+
 bool attn_window_supported(const AttnArgs& a) {
     const bool ragged = a.rag_off != nullptr;
     const int kalign = a.kv_bf16 ? 8 : 4;   // 16-byte key loads
@@ -206,7 +401,12 @@ void launch_attn_window(const AttnArgs& a, hipStream_t stream) {
         if (a.kv_bf16) hipLaunchKernelGGL((k_attn_window<true, true>), grid, dim3(256), 0, stream, a, qtiles);
         else hipLaunchKernelGGL((k_attn_window<false, true>), grid, dim3(256), 0, stream, a, qtiles);
     } else {
-        hipLaunchKernelGGL((k_attn_window<false, false>), grid, dim3(256), 0, stream, a, qtiles);
+        // (measured: Mimi phase of the benchmark batch 12.85 -> 12.50 ms with the shared tiles, 128 queries per block; 64 queries per block -- two waves, 10 tiles
+        // of which a wave uses 9 instead of 12 / 9 -- 12.7 ms; profiles/r4_mimi_ab.txt)
+        if ((int64_t)(a.pos_base + a.rows_per_seg) * a.k_row_stride < (1ll << 31)) {
+            const int qblocks = (a.rows_per_seg + 127) / 128;
+            hipLaunchKernelGGL(k_attn_window_lds<4>, dim3(a.heads, (unsigned)(segs * qblocks)), dim3(256), 0, stream, a, qblocks);
+        } else hipLaunchKernelGGL((k_attn_window<false, false>), grid, dim3(256), 0, stream, a, qtiles);
     }
 }
 
