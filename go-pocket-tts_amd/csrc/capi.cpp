@@ -76,6 +76,15 @@ const char* ptts_last_error(void) { return last_error_ref().c_str(); }
 const char* ptts_version(void) { return "ptts-hip 0.2 gfx950"; }
 const char* ptts_debug_last_attention_kernel(void) { return g_last_attn_kernel; }
 
+int ptts_debug_flow_cluster_inject(ptts_model* h, int32_t block) {
+    return guard([&] {
+        if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");
+        if (block < 0 || block > h->m->d.flow_depth) throw Error(PTTS_EINVAL, "ptts-hip: flow-net block out of range");
+        std::lock_guard<std::mutex> lock(h->m->mu);
+        h->m->fc_inject = block;
+    });
+}
+
 int64_t ptts_debug_launch_counts(int32_t on, char* out, int64_t cap) {
     static thread_local std::map<std::string, int64_t> census;
     std::string s;

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(FC_THREADS) void k_flow_cluster(FlowClusterArgs a) 
             {
                 const float h[4] = {silu1(acc[0] + bias0.x), silu1(acc[1] + bias0.y), silu1(acc[2] + bias0.z), silu1(acc[3] + bias0.w)};
                 if (STAMP && wave == 0 && r == 2) { if (h[0] == 1.2345e-30f) FC_STAMP(60); FC_STAMP(58); }
-                if (s_ok) fc_publish(rs, BUF1 + pub_off, base + 2 * r + 1, h);
+                if (s_ok && !(a.inject && tile == 0 && cb == 7 && r == a.inject - 1)) fc_publish(rs, BUF1 + pub_off, base + 2 * r + 1, h);   // (inject: ptts_debug_flow_cluster_inject)
             }
             if (STAMP && wave == 0 && r == 2) FC_STAMP(57);
             if (wave == 0) FC_STAMP(2 + 4 * r);

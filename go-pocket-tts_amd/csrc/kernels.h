@@ -281,6 +281,7 @@ struct FlowClusterArgs {
     const void* w2[FC_MAX_DEPTH] = {}; const float* b2[FC_MAX_DEPTH] = {};
     unsigned long long* xbuf = nullptr;   // granules {value, tag}: [tile of 12 rows][2][16][C]
     unsigned long long* stamps = nullptr; // measurement only (null in the product): [workgroup][64] timestamps
+    int inject = 0;                       // test hook (0 in the product): workgroup 7 of tile 0 publishes nothing for mlp0 of block inject - 1 -> its peers' sweeps time out
     unsigned* sync = nullptr;             // [tile] the tag base of the tile's next launch, 32 words apart; word 32 * 8: fault flags
 };
 constexpr size_t kFlowClusterXbufBytes = (size_t)6 * 2 * 16 * 512 * 8,   // six 12-row tiles

@@ -786,6 +786,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
             }
             fa.xbuf = b.fc_xbuf.as<unsigned long long>(); fa.sync = b.fc_sync.as<unsigned>();
             if (b.fc_stamps.p) fa.stamps = b.fc_stamps.as<unsigned long long>();
+            if (m.fc_inject && !b.capturing) { fa.inject = m.fc_inject; m.fc_inject = 0; }
             if (flow_cluster_supported(fa, C)) {
                 // (not a launch of the step linear: the bench's per-launch events and byte counts -- Prof -- leave it out; bench.py reports it from the kernel trace)
                 launch_flow_cluster(fa, s);

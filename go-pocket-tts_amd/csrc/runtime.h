@@ -64,6 +64,7 @@ struct Model {
     std::vector<std::unique_ptr<DevBuf>> ws;       // grow-only workspaces (Mimi decode, prefill)
     std::unique_ptr<Batch> cached_batch;
     Prof prof;
+    int fc_inject = 0;   // test hook: the next k_flow_cluster launch (plain launches) runs with FlowClusterArgs::inject = this, once
 
     ~Model();
     template <class T> const T* at(size_t off) const { return off == NONE ? nullptr : reinterpret_cast<const T*>(arena + off); }

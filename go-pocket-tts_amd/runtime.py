@@ -93,7 +93,7 @@ ABI_SYMBOLS = [
     "ptts_plan_create", "ptts_plan_create_bytes", "ptts_plan_arena_bytes", "ptts_model_open_planned", "ptts_plan_free",
     "ptts_generate", "ptts_free_result", "ptts_text_embeddings", "ptts_batch_new", "ptts_batch_free", "ptts_batch_reset",
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
-    "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_noise_rows", "ptts_speaker_project", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
+    "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_debug_flow_cluster_inject", "ptts_noise_rows", "ptts_speaker_project", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
@@ -178,6 +178,7 @@ def lib():
         L.ptts_voice_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.ptts_voice_open_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.ptts_mimi_layer_piece.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int32, _FP]
+        L.ptts_debug_flow_cluster_inject.argtypes = [C.c_void_p, C.c_int32]
         L.ptts_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.ptts_profile_read.argtypes = [C.c_void_p, C.POINTER(_Profile)]
         L.ptts_op_linear.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int64, C.c_int64, _FP]
@@ -389,6 +390,10 @@ class Model:
         out = np.empty((x.shape[0], 3 * x.shape[1]), np.float32)
         _check(lib().ptts_mimi_layer_piece(self.h, layer, 0, _fp(x), x.shape[0], pos0, rows_per_seg, _fp(out)))
         return out
+
+    def debug_flow_cluster_inject(self, block: int) -> None:
+        """Test hook: the next plain-launched AR step's k_flow_cluster runs with one workgroup withholding its publish for flow-net block `block` (1-based)."""
+        _check(lib().ptts_debug_flow_cluster_inject(self.h, int(block)))
 
     def mimi_layer_ffn(self, layer: int, x) -> np.ndarray:
         """x + layer_scale_2 * linear2(gelu(linear1(norm2(x)))) of Mimi decoder-transformer layer `layer` on rows x [R, 512]."""

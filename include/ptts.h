@@ -394,6 +394,12 @@ const char* ptts_debug_last_attention_kernel(void);
  * run their launches on the calling thread (every entry point except the dispatcher's) are covered. */
 int64_t ptts_debug_launch_counts(int32_t on, char* out, int64_t cap);
 
+/* Test hook for the bounded hand-offs of k_flow_cluster (csrc/flow_cluster.hip): the model's NEXT plain-launched AR step runs the flow net's residual
+ * blocks with one workgroup withholding what it should publish for block `block` (1-based; 0 clears).  Its peers' sweeps give up after their bound, the
+ * launch runs to its end, and the call that contained the step fails with PTTS_ENODEVICE ("hand-off timed out"); the exchange state is cleared, the next
+ * call is clean.  Nothing in the product sets it. */
+int ptts_debug_flow_cluster_inject(ptts_model* m, int32_t block);
+
 const char* ptts_version(void);
 
 #ifdef __cplusplus

@@ -97,3 +97,25 @@ def test_cluster_hand_offs_are_reproducible_beside_a_running_decoder(pkg, full):
         gm.close()
     finally:
         os.environ.pop("PTTS_MIMI_CHUNK", None)
+
+
+def test_a_withheld_publish_times_out_fails_the_call_and_leaves_the_next_one_clean(pkg, full):
+    """Every sweep of the kernel is bounded: with one workgroup withholding what it should publish (test hook), its peers give up after the bound instead
+    of spinning, the launch runs to its end, the call fails with the hand-off error -- and the exchange state is cleared, so the same model's next call
+    gives the bits of an undisturbed one."""
+    cfg, path, voice = full
+    gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=16)
+    v = gm.upload_voice(pkg.VoiceModelState(voice))
+    prompts = [p.tolist() for p in pkg.synth.make_prompts(13, 25, 4000, seed=5)]   # 13 rows: two tiles, the second ragged
+    c = pkg.RuntimeGenerateConfig(max_steps=6, eos_threshold=float("inf"), frames_after_eos=3, device_voice=v, want_latents=True)
+    good = gm.generate_batch(prompts, [c] * 13)
+    gm.debug_flow_cluster_inject(3)
+    with pytest.raises(Exception) as ei:
+        gm.generate_batch(prompts, [c] * 13)
+    assert "hand-off timed out" in str(ei.value), str(ei.value)
+    again = gm.generate_batch(prompts, [c] * 13)
+    for a, b in zip(again, good):
+        np.testing.assert_array_equal(a.latents, b.latents)
+        np.testing.assert_array_equal(a.pcm, b.pcm)
+    v.close()
+    gm.close()
