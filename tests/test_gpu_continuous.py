@@ -290,3 +290,32 @@ def test_full_size_64_slots_mixed_lengths_finite_eos_against_stand_alone_and_ora
     om.close()
     dv.close()
     gm.close()
+
+
+def test_a_timed_out_hand_off_fails_the_requests_in_flight_and_the_engine_comes_back(pkg):
+    """The continuous engine runs k_flow_cluster in every step at the b6369a24 shapes.  With one of its workgroups made to withhold a publish (test hook,
+    tests/test_gpu_flow_cluster.py) the engine's read-back carries the fault word: everyone in flight is answered with the hand-off error, the engine is
+    rebuilt, and the requests sent afterwards get their stand-alone audio."""
+    import bench
+    cfg = pkg.synth.SynthConfig.full()
+    path = bench.checkpoint_path(pkg, "BF16", 0, lambda: None)
+    gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=8)
+    dv = gm.upload_voice(pkg.VoiceModelState(bench.voice_modules(pkg, cfg)))
+    prompts = [p.tolist() for p in pkg.synth.make_prompts(6, 25, 4000, seed=21)]
+    cfgs = [pkg.RuntimeGenerateConfig(max_steps=20 + 2 * i, eos_threshold=float("inf"), frames_after_eos=3, device_voice=dv, want_latents=True) for i in range(6)]
+    want = gm.generate_batch(prompts, cfgs)
+    d = pkg.Dispatcher([gm], max_batch=8, window_us=2000, continuous=True, cont_kv_capacity=256, cont_max_steps=64)
+    try:
+        gm.debug_flow_cluster_inject(2)
+        got, errs = run_clients(d, prompts, cfgs)
+        assert all(e is not None for e in errs), [type(e).__name__ if e else r.n_frames for e, r in zip(errs, got)]
+        assert any("hand-off timed out" in str(e) or "request failed" in str(e) for e in errs), [str(e) for e in errs]
+        got, errs = run_clients(d, prompts, cfgs)
+        assert all(e is None for e in errs), [str(e) for e in errs]
+        for i in range(6):
+            assert got[i].n_frames == want[i].n_frames
+            np.testing.assert_allclose(got[i].latents[:4], want[i].latents[:4], rtol=0, atol=2e-2 * float(np.abs(want[i].latents).max()))
+    finally:
+        d.close()
+        dv.close()
+        gm.close()
