@@ -24,6 +24,8 @@
 #include <algorithm>
 #include <cmath>
 #include <deque>
+#include <map>
+#include <mutex>
 
 #include "runtime.h"
 
@@ -35,7 +37,27 @@ constexpr int kDecoderCUs = 128;      // CUs open to the decoder's stream (of 25
 constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
 constexpr int kDecodeMaxAge = 8;      // ... or the oldest has waited this many groups of steps (a caller waiting for audio is a caller not sending its next request)
 constexpr int kBandFrames = 16, kBandPercent = 16;   // a decode pads everything to its longest member: members within max(16 frames, 16 %) of it
-constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
+
+// the decoder's CU-masked stream of a GPU, shared by the continuous engines on it (created with the first, destroyed with the last)
+std::mutex g_dec_mu;
+std::map<int, std::pair<hipStream_t, int>> g_dec_streams;
+hipStream_t decoder_stream_acquire(int device) {
+    std::lock_guard<std::mutex> lock(g_dec_mu);
+    auto& ent = g_dec_streams[device];
+    if (!ent.first) {
+        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < kDecoderCUs; i++) mask[i >> 5] |= 1u << (i & 31);
+        PTTS_HIP(hipExtStreamCreateWithCUMask(&ent.first, 8, mask));
+    }
+    ent.second++;
+    return ent.first;
+}
+void decoder_stream_release(int device) {
+    std::lock_guard<std::mutex> lock(g_dec_mu);
+    auto it = g_dec_streams.find(device);
+    if (it == g_dec_streams.end()) return;
+    if (--it->second.second <= 0) { (void)hipStreamDestroy(it->second.first); g_dec_streams.erase(it); }
+}constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
 }
 
 struct ContEngine {
@@ -107,7 +129,7 @@ struct ContEngine {
         (void)hipStreamSynchronize(m.stream);
         (void)hipStreamSynchronize(m.stream2);
         if (io) (void)hipStreamSynchronize(io);   // (the model's second stream: not ours to destroy)
-        if (dec) { (void)hipStreamSynchronize(dec); (void)hipStreamDestroy(dec); }
+        if (dec) { (void)hipStreamSynchronize(dec); decoder_stream_release(m.device); }
         if (trace_path && !trace.empty()) {
             if (FILE* f = fopen(trace_path, "a")) {
                 fprintf(f, "# gap_us dur_us n_gen steps admitted decodes_started decoding joining\n");
@@ -182,12 +204,7 @@ ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
         // (steps 6x slower for the length of a decode, PTTS_CONT_TRACE).  Confined to half of the CUs (CU-mask bits are dealt round the XCDs: 16 of each
         // XCD's 32) the decoder takes twice as long and the steps beside it 1.4x instead of 6x: +5 % throughput at 128 clients (96 / 160 / 192 CUs:
         // +3 / +4 / +0 %; 64: the decoder falls behind), profiles/r4_serve_sweep.txt.
-        const int n_cu = kDecoderCUs;
-        if (n_cu > 0 && n_cu < 256) {
-            uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (int i = 0; i < n_cu; i++) mask[i >> 5] |= 1u << (i & 31);
-            PTTS_HIP(hipExtStreamCreateWithCUMask(&e->dec, 8, mask));
-        } else PTTS_HIP(hipStreamCreateWithFlags(&e->dec, hipStreamNonBlocking));
+        e->dec = decoder_stream_acquire(m.device);   // ONE per GPU: the engines of a GPU (ptts_model_share) queue their decodes on the same confined stream
     }
     b.io_stream = e->io;
     for (DevBuf& db : e->adm_dev) db.ensure((size_t)slots * sizeof(SlotAdmit));
