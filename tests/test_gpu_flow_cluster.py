@@ -119,3 +119,27 @@ def test_a_withheld_publish_times_out_fails_the_call_and_leaves_the_next_one_cle
         np.testing.assert_array_equal(a.pcm, b.pcm)
     v.close()
     gm.close()
+
+
+def test_two_euler_steps_per_frame_run_the_cluster_twice_and_match_the_launches(pkg, full):
+    """lsd_decode_steps = 2 (flow_lm.go:311-353): the flow net runs twice per frame, the second time on the first's Euler state -- two k_flow_cluster launches per
+    AR step whose exchange tags follow on from each other.  Against the 2 x 12 launches, free-running over 5 frames: the same bits."""
+    cfg, path, voice = full
+    prompts = [p.tolist() for p in pkg.synth.make_prompts(9, 25, 4000, seed=31)]
+    outs = []
+    for cluster in ("1", "0"):
+        os.environ["PTTS_FLOW_CLUSTER"] = cluster
+        try:
+            gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=16)
+            v = gm.upload_voice(pkg.VoiceModelState(voice))
+            c = pkg.RuntimeGenerateConfig(max_steps=5, lsd_decode_steps=2, eos_threshold=float("inf"), frames_after_eos=3, device_voice=v, want_latents=True)
+            pkg.runtime.launch_counts(True)
+            outs.append(gm.generate_batch(prompts, [c] * 9))
+            counts = pkg.runtime.launch_counts(False)
+            assert counts.get("k_flow_cluster", 0) == (10 if cluster == "1" else 0), counts
+            v.close()
+            gm.close()
+        finally:
+            os.environ.pop("PTTS_FLOW_CLUSTER", None)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a.latents, b.latents)
