@@ -177,6 +177,55 @@ def open_model(pkg, path, wl, rank, world, device):
     return model, arena
 
 
+STEP_WEIGHT_PARAMS = 85_263_360     # parameters every AR step streams once for the whole batch
+KV_ELEMS_PER_KEY = 2 * 6 * 1024      # K and V, 6 layers, d_model 1024: elements one cached position holds per utterance
+PROMPT_KEYS = 125 + 25               # the benchmark's cache before the first step: 125-frame voice state + 25 prompt tokens
+
+
+def step_level(batch, frames, ar_loop_ms, weight_elem=2, kv_elem=2):
+    """The WHOLE AR step against HBM (beside the per-kernel entry): SURVEY.md 8(d)'s bytes per step -- every step weight once for the batch
+    plus the keys and values each utterance's attention reads (cache length averaged over the run) -- over the measured time of a step."""
+    us = 1e3 * ar_loop_ms / max(1, frames)
+    mean_keys = PROMPT_KEYS + (frames - 1) / 2.0
+    nbytes = STEP_WEIGHT_PARAMS * weight_elem + batch * KV_ELEMS_PER_KEY * kv_elem * mean_keys
+    gbs = nbytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4), "us_per_step": round(us, 2),
+            "algorithmic_bytes_per_step": round(nbytes), "rows": batch,
+            "note": "step-level: (step weights once + KV bytes read by the batch, SURVEY.md 8d) / (AR-loop device time / steps)"}
+
+
+def step_level_fraction(batch, frames, step_us, weight_elem=2, kv_elem=2):
+    return step_level(batch, frames, step_us * frames * 1e-3, weight_elem, kv_elem)["frac"]
+
+
+def wide_batch_pass(pkg, model, wl, batch, voice, steps, sync):
+    """Labelled extra (never the headline): the same 10-s utterances, `batch` of them per call through ONE engine (the AR step's kernels take up to 256
+    rows: row tiles of the step linear, 12-row tiles of the flow-net cluster; the decoder goes through its workspace in groups of 64)."""
+    eng = model.share()
+    try:
+        eng.set_max_batch(batch)
+        eng.set_use_graph(True)
+        wlb = dict(wl, batch=batch)
+        prompts = pkg.synth.make_prompts(batch, 25, 4000, seed=42)
+        e, lat, _ = run_workload(pkg, eng, wlb, prompts, voice, steps, 2, lambda: None, sync)
+        cfgs = gen_cfgs(pkg, wlb, batch, voice)
+        toks = [np.ascontiguousarray(p, np.int64) for p in prompts]
+        eng.profile_enable(2)
+        try:
+            eng.generate_batch(toks, cfgs)
+            ph = eng.profile_read()
+        finally:
+            eng.profile_enable(False)
+        return {"value": round(batch * wl["frames"] * FRAME_SEC * steps / e, 1), "unit": "x real-time", "ms_per_step": round(1e3 * e / steps, 3),
+                "p50_utterance_latency_ms": round(1e3 * statistics.median(lat), 2),
+                "phases_ms": {"prefill": round(ph["prefill_ms"], 3), "ar_loop": round(ph["ar_loop_ms"], 3), "mimi": round(ph["mimi_ms"], 3)},
+                "step_level": step_level(batch, wl["frames"], ph["ar_loop_ms"]),
+                "config": f"labelled extra, not the headline: {batch} utterances x {wl['frames']} frames in ONE call of one engine (ptts_model_set_max_batch {batch}), "
+                          "graph replay, bf16 weights + KV, the decoder in groups of 64 utterances"}
+    finally:
+        eng.close()
+
+
 def gen_cfgs(pkg, wl, n, voice, **kw):
     base = dict(temperature=0.0, eos_threshold=float("inf"), max_steps=wl["frames"], lsd_decode_steps=1, frames_after_eos=3, device_voice=voice)
     base.update(kw)
@@ -286,6 +335,7 @@ def roofline_pass(pkg, model, wl, prompts, voice, traffic=None):
          "achieved_with_activations": round(with_act, 1), "frac_with_activations": round(with_act / HBM_PEAK_GBS, 4),
          "bytes_per_launch_with_activations": round(prof["algorithmic_bytes"] / n),
          "phases_ms": {"prefill": round(prof["prefill_ms"], 3), "ar_loop": round(prof["ar_loop_ms"], 3), "mimi": round(prof["mimi_ms"], 3)}}
+    r["step_level"] = step_level(len(prompts), wl["frames"], prof["ar_loop_ms"], {0: 4, 1: 2, 2: 1}[wl["weights"]], 2 if wl["kv"] else 4)
     # the same kernel's mean as rocprofv3 reports it for the same workload under graph replay (a child pass of this run).  Under the profiler every
     # launch is a little longer and the chip's clock a little lower (2-3 %), the in-process events see the kernels launched one by one; where the two
     # differ, `frac` is priced with the LONGER one, and both stand in the line.
@@ -630,6 +680,13 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"[bench] roofline pass failed: {e}")
             result["roofline"] = None
+    if rank == 0 and world == 1 and not args.no_two_engines and args.workload == "b64_10s_bf16":
+        # more rows per AR step through one engine (a step's time hardly depends on its rows): labelled extras beside the unchanged 64-per-GPU headline
+        for bw in (128, 256):
+            try:
+                result[f"b{bw}"] = wide_batch_pass(pkg, model, wl, bw, voice, max(3, args.steps // 2), sync)
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] b{bw} pass failed: {e}")
     if rank == 0 and world == 1 and not args.no_b1 and not args.no_two_engines and args.workload == "b64_10s_bf16":
         # serving configuration, reported beside the headline (not `value`): two engines over the same weights, each running
         # the same 64-utterance passes back to back, so that one pass's Mimi decode overlaps the other's prefill + AR loop

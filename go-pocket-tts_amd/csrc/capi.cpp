@@ -38,6 +38,7 @@ ptts_opts resolve_opts(const ptts_opts* o) {
     ptts_default_opts(&r);
     if (o) r = *o;
     if (r.max_batch <= 0) r.max_batch = 64;
+    if (r.max_batch > kStepMaxRows) throw Error(PTTS_EINVAL, strfmt("ptts-hip: max_batch %d exceeds the %d utterances one AR step takes", r.max_batch, kStepMaxRows));
     if (r.weights != PTTS_WEIGHTS_F32 && r.weights != PTTS_WEIGHTS_BF16 && r.weights != PTTS_WEIGHTS_INT8) throw Error(PTTS_EINVAL, "ptts-hip: unknown weights mode");
     if (r.kv != PTTS_KV_F32 && r.kv != PTTS_KV_BF16) throw Error(PTTS_EINVAL, "ptts-hip: unknown kv mode");
     return r;
@@ -186,6 +187,15 @@ int ptts_model_set_use_graph(ptts_model* m, int32_t use_graph) {
         if (!m || !m->m) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
         std::lock_guard<std::mutex> lock(m->m->mu);   // not under a running generate
         m->m->opts.use_graph = use_graph ? 1 : 0;
+    });
+}
+
+int ptts_model_set_max_batch(ptts_model* m, int32_t max_batch) {
+    return guard([&] {
+        if (!m || !m->m) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        if (max_batch < 1 || max_batch > kStepMaxRows) throw Error(PTTS_EINVAL, strfmt("ptts-hip: max_batch %d outside [1, %d]", max_batch, kStepMaxRows));
+        std::lock_guard<std::mutex> lock(m->m->mu);   // not under a running generate
+        m->m->opts.max_batch = max_batch;
     });
 }
 

@@ -168,7 +168,7 @@ struct ContEngine {
 };
 
 ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
-    if (slots <= 0 || slots > 64) throw Error(PTTS_EINVAL, "continuous batch: 1..64 slots (the AR step kernels take up to 64 rows)");
+    if (slots <= 0 || slots > kStepMaxRows) throw Error(PTTS_EINVAL, strfmt("continuous batch: 1..%d slots (the rows one AR step takes)", kStepMaxRows));
     kv_cap = (std::max(kv_cap, 64) + 63) / 64 * 64;
     std::unique_ptr<ContEngine> e(new ContEngine(m));
     std::lock_guard<std::mutex> lock(m.mu);

@@ -39,7 +39,7 @@ typedef unsigned fc_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int FC_C = 512;                   // width of the flow net (host: flow_cluster_supported)
 constexpr int FC_RB = 2048, FC_CMASK = 127;   // LDS image: bytes and 16-byte chunks (- 1) per row (bf16 x 1024: k_skinny's NJ <= 4 image)
 constexpr unsigned FC_SPIN_LIMIT = 1u << 15;  // sweeps of a row before giving up (a pass is >= 0.5 us: >= 16 ms)
-constexpr int FC_FAULT_WORD = 32 * 8;
+constexpr int FC_FAULT_WORD = 32 * kFlowClusterMaxTiles;   // behind the tiles' tag-base words (32 words apart)
 
 union FcFrag {
     fc_bf16x8 v;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void fc_publish(RS rs, int voff, unsigned tag, const 
 // roles apart nobody waits for an acknowledgement (the multiplying waves next touch memory when they need the following linear's weights, a hop later),
 // the stagers sweep while the products run, and one barrier per linear ("image complete") is the only meeting point: the image of linear p + 1 cannot
 // be written before this workgroup's own multiplying waves have published linear p -- by which time they have read image p.
-constexpr int FC_ROWS = 12;          // rows per tile: one per staging wave
+constexpr int FC_ROWS = kFlowClusterRows;          // rows per tile: one per staging wave
 constexpr int FC_THREADS = 64 * (4 + FC_ROWS);
 constexpr int FC_TILE_GRANULES = 2 * 16 * FC_C;   // granules of a tile's two buffers (16-row pitch)
 
@@ -296,11 +296,20 @@ __global__ __launch_bounds__(FC_THREADS) void k_flow_cluster(FlowClusterArgs a) 
 }
 
 bool flow_cluster_supported(const FlowClusterArgs& a, int C) {
-    if (C != FC_C || a.rows <= 0 || a.rows > 64 || a.depth <= 0 || a.depth > FC_MAX_DEPTH || a.ldmod % 4 != 0 || !a.xbuf || !a.sync) return false;
+    if (C != FC_C || a.rows <= 0 || a.rows > kFlowClusterMaxTiles * kFlowClusterRows || a.depth <= 0 || a.depth > FC_MAX_DEPTH || a.ldmod % 4 != 0 || !a.xbuf || !a.sync) return false;
     if (!aligned16(a.fx_in) || !aligned16(a.fx_out) || !aligned16(a.ada)) return false;
     for (int r = 0; r < a.depth; r++)
         if (!a.w0[r] || !a.w2[r] || !a.b0[r] || !a.b2[r] || !a.ln_w[r] || !a.ln_b[r] || !aligned16(a.b0[r]) || !aligned16(a.b2[r]) || !aligned16(a.ln_w[r]) || !aligned16(a.ln_b[r])) return false;
     return true;
+}
+
+bool flow_cluster_fits(int rows, int device) {
+    // A tile's eight workgroups hand rows to each other inside the launch and spin (bounded) on each other's granules: the whole grid must be resident at
+    // once.  A workgroup is 16 waves and 64 KB of LDS -- one per CU on gfx950 -- so the grid must not exceed what the device holds of them.
+    int cus = 0, per_cu = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || cus <= 0) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_flow_cluster<false>, FC_THREADS, 0) != hipSuccess || per_cu <= 0) { (void)hipGetLastError(); return false; }
+    return 8 * ((rows + FC_ROWS - 1) / FC_ROWS) <= cus * per_cu;
 }
 
 void launch_flow_cluster(const FlowClusterArgs& a, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1) {

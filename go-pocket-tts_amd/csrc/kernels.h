@@ -60,6 +60,7 @@ struct GemmArgs {
     int M = 0, N = 0, K = 0;
     int aop = AOP_NONE, epi = EPI_NONE;
 };
+constexpr int kStepMaxRows = 256;       // rows (utterances) one AR step takes: the step kernels' grids grow by row tiles, the flow-net cluster by 12-row tiles
 constexpr int kSkinnyChunkRows = 256;   // up to this many rows a GEMM on a step matrix runs as 64-row chunks of the step kernel (launch_gemm)
 void launch_gemm(const GemmArgs& a, hipStream_t stream);
 bool launch_gemm_rope(const GemmArgs& a, hipStream_t stream);   // a product with the RoPE epilogue (GemmArgs::rope_cos) on k_gemm3; false: the shape is not taken (the caller rotates in a second launch)
@@ -74,7 +75,7 @@ bool gemm5_supported(const GemmArgs& a);   // gemm3's data movement without its 
 void launch_gemm5(const GemmArgs& a, hipStream_t stream);
 extern thread_local int g_gemm5_cfg;
 
-// Weight-streaming linear for the AR step (M <= 64 rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
+// Weight-streaming linear for the AR step (M <= kStepMaxRows rows): C[M,N] = epi(prologue(A)[M,K] * W[N,K]^T).
 // splitk > 1: raw partial sums go to partial[z][M][N] (no bias / epilogue); a consumer adds them up in a fixed order.
 // The optional prologue (SkinnyFuse; needs K == row width <= 1024, splitk == 1) folds the preceding residual update
 // and LayerNorm into the activation staging.
@@ -282,10 +283,15 @@ struct FlowClusterArgs {
     unsigned long long* xbuf = nullptr;   // granules {value, tag}: [tile of 12 rows][2][16][C]
     unsigned long long* stamps = nullptr; // measurement only (null in the product): [workgroup][64] timestamps
     int inject = 0;                       // test hook (0 in the product): workgroup 7 of tile 0 publishes nothing for mlp0 of block inject - 1 -> its peers' sweeps time out
-    unsigned* sync = nullptr;             // [tile] the tag base of the tile's next launch, 32 words apart; word 32 * 8: fault flags
+    unsigned* sync = nullptr;             // [tile] the tag base of the tile's next launch, 32 words apart; word 32 * kFlowClusterMaxTiles: fault flags
 };
-constexpr size_t kFlowClusterXbufBytes = (size_t)6 * 2 * 16 * 512 * 8,   // six 12-row tiles
-                  kFlowClusterSyncBytes = (size_t)(32 * 8 + 32) * 4;
+constexpr int kFlowClusterRows = 12;                                        // rows of the batch per tile (8 workgroups each)
+constexpr int kFlowClusterMaxTiles = (kStepMaxRows + kFlowClusterRows - 1) / kFlowClusterRows;   // 22 tiles = 176 workgroups at 256 rows: one per CU, all resident at once
+constexpr size_t kFlowClusterTileBytes = (size_t)2 * 16 * 512 * 8;          // a tile's two granule buffers
+constexpr size_t kFlowClusterSyncBytes = (size_t)(32 * kFlowClusterMaxTiles + 32) * 4;
+inline size_t flow_cluster_xbuf_bytes(int rows) { return (size_t)((rows + kFlowClusterRows - 1) / kFlowClusterRows) * kFlowClusterTileBytes; }
+// whether a grid of 8 workgroups per 12-row tile is resident at once on `device` (the hand-offs between a tile's workgroups spin: they need their peers running)
+bool flow_cluster_fits(int rows, int device);
 bool flow_cluster_supported(const FlowClusterArgs& a, int C);
 void launch_flow_cluster(const FlowClusterArgs& a, hipStream_t stream, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
 

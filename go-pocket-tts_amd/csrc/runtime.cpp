@@ -184,11 +184,12 @@ const float* Model::tcomb_for(int n) {
 // ------------------------------------------------------------------------------------------------
 Batch::~Batch() {
     if (fc_stamps.p) {   // (PTTS_FC_STAMPS=<file>: the timestamps of the batch's LAST k_flow_cluster launch, one line per workgroup)
-        std::vector<unsigned long long> h(64 * 64);
+        constexpr int kWg = 8 * kFlowClusterMaxTiles;
+        std::vector<unsigned long long> h((size_t)kWg * 64);
         if (const char* path = getenv("PTTS_FC_STAMPS"))
             if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(h.data(), fc_stamps.p, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
                 if (FILE* f = fopen(path, "a")) {
-                    for (int blk = 0; blk < 64; blk++) {
+                    for (int blk = 0; blk < kWg; blk++) {
                         if (!h[(size_t)blk * 64]) continue;
                         fprintf(f, "wg %d:", blk);
                         for (int i = 0; i < 64; i++) fprintf(f, " %llu", h[(size_t)blk * 64 + i]);
@@ -207,6 +208,7 @@ static bool open_linears(Batch& b, StepOpenLinears& lin);
 
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     if (n_slots <= 0) throw Error(PTTS_EINVAL, "ptts-hip: batch needs at least one slot");
+    if (n_slots > kStepMaxRows) throw Error(PTTS_EINVAL, strfmt("ptts-hip: a batch takes at most %d slots (the AR step's kernels), asked for %d", kStepMaxRows, n_slots));
     if (cap <= 0 || cap > ROPE_SEQ) throw Error(PTTS_EINVAL, strfmt("ptts-hip: kv capacity %d outside (0, %d] (RoPE table rows, flow_transformer.go:505)", cap, ROPE_SEQ));
     m.use_device();
     const Desc& d = m.d;
@@ -259,7 +261,8 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     {   // flow_cluster.hip: bf16 step copies of every residual block's linears, the width it is built for
         const char* sw = getenv("PTTS_FLOW_CLUSTER");   // A/B switch, read per batch: 0 = the 2 x depth launches (tests compare the two forms bit for bit)
         const bool off = sw && sw[0] == '0';
-        bool ok = !off && d.flow_dim == 512 && d.flow_depth > 0 && d.flow_depth <= FC_MAX_DEPTH && n_slots <= 64;
+        bool ok = !off && d.flow_dim == 512 && d.flow_depth > 0 && d.flow_depth <= FC_MAX_DEPTH && n_slots <= kStepMaxRows &&
+                  flow_cluster_fits(n_slots, m.device);   // (every workgroup of the grid resident at once: its hand-offs spin on its peers)
         for (int r = 0; ok && r < d.flow_depth; r++) {
             const auto& rb = d.rb[r];
             for (const Lin* l : {&rb.mlp0, &rb.mlp2}) ok = ok && l->in == 512 && l->out == 512 && l->bf16 && !l->wt_i8 && l->wt != NONE && l->b != NONE;
@@ -267,10 +270,10 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
         }
         b->fc_ok = ok;
         if (ok) {
-            b->fc_xbuf.ensure(kFlowClusterXbufBytes); b->fc_sync.ensure(kFlowClusterSyncBytes);
-            PTTS_HIP(hipMemsetAsync(b->fc_xbuf.p, 0, kFlowClusterXbufBytes, m.stream));
+            b->fc_xbuf.ensure(flow_cluster_xbuf_bytes(n_slots)); b->fc_sync.ensure(kFlowClusterSyncBytes);
+            PTTS_HIP(hipMemsetAsync(b->fc_xbuf.p, 0, flow_cluster_xbuf_bytes(n_slots), m.stream));
             PTTS_HIP(hipMemsetAsync(b->fc_sync.p, 0, kFlowClusterSyncBytes, m.stream));
-            if (getenv("PTTS_FC_STAMPS")) { b->fc_stamps.ensure(64 * 64 * 8); PTTS_HIP(hipMemsetAsync(b->fc_stamps.p, 0, 64 * 64 * 8, m.stream)); }
+            if (getenv("PTTS_FC_STAMPS")) { b->fc_stamps.ensure((size_t)8 * kFlowClusterMaxTiles * 64 * 8); PTTS_HIP(hipMemsetAsync(b->fc_stamps.p, 0, (size_t)8 * kFlowClusterMaxTiles * 64 * 8, m.stream)); }
         }
     }
     PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(2 + 2 * B), hipHostMallocDefault));
@@ -639,7 +642,7 @@ static bool open_linears(Batch& b, StepOpenLinears& lin) {
 void flow_cluster_fault(Batch& b) {
     hipStream_t s = b.m->stream;
     (void)hipStreamSynchronize(s);
-    (void)hipMemsetAsync(b.fc_xbuf.p, 0, kFlowClusterXbufBytes, s);
+    (void)hipMemsetAsync(b.fc_xbuf.p, 0, flow_cluster_xbuf_bytes(b.B), s);
     (void)hipMemsetAsync(b.fc_sync.p, 0, kFlowClusterSyncBytes, s);
     (void)hipStreamSynchronize(s);
     throw Error(PTTS_ENODEVICE, "ptts-hip: the flow net's in-launch hand-off timed out (k_flow_cluster); the batch's frames were discarded");
@@ -1378,9 +1381,6 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
     auto too_long = [&](int frames) {
         return Error(PTTS_EINVAL, strfmt("generate: mimi_decode: ops: rope cos/sin sequence length too small for pos=0 seq=%lld", (long long)frames * d.up_stride));
     };
-    MimiWs mw;
-    mimi_setup(m, mw, B, T);
-    mimi_zero_history(m, mw, m.stream2);   // nine small launches: under the AR loop instead of between the loop and the decoder
     DevBuf& pcm = m.work(7, (size_t)B * T * spf * sizeof(float));
     const char* env_chunk = getenv("PTTS_MIMI_CHUNK");
     int chunk = env_chunk && atoi(env_chunk) > 0 ? atoi(env_chunk) : 1 << 30;   // default: decode after the loop (measured: overlapping
@@ -1426,6 +1426,13 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         }
         if (any_s16) stream_s16 = &m.work(8, (size_t)B * T * spf * sizeof(int16_t));
     }
+    // Decoder workspace (~2.7 MB of f32 activations per latent frame and utterance).  A batch of more than kMimiGroup utterances that is decoded in one go after the
+    // loop (the default) goes through the decoder group after group in the SAME buffers (stream order keeps them apart); a batch whose frame ranges are decoded under
+    // the loop (streaming, PTTS_MIMI_CHUNK) needs every utterance's history from range to range and keeps one workspace for all of them.
+    const int dec_group = (B > kMimiGroup && !streaming && chunk > ms_max) ? kMimiGroup : B;
+    MimiWs mw;
+    mimi_setup(m, mw, dec_group, T);
+    mimi_zero_history(m, mw, m.stream2);   // nine small launches: under the AR loop instead of between the loop and the decoder
     int f_done = 0, f_emitted = 0, steps_run = 0;
     size_t ev_used = 0;
     auto next_event = [&]() {
@@ -1440,7 +1447,21 @@ static void generate_chunk(Model& m, const ptts_request* reqs, const std::vector
         hipEvent_t e = next_event();
         PTTS_HIP(hipEventRecord(e, s));
         PTTS_HIP(hipStreamWaitEvent(m.stream2, e, 0));
-        mimi_range(m, mw, b.latents.as<float>(), (int64_t)b.max_steps * ld, f_done, f1, pcm.as<float>(), nullptr, m.stream2, f_done == 0 ? pcm_rows : nullptr, rows_used);
+        const int64_t lstride = (int64_t)b.max_steps * ld;
+        int direct = 0, groups = 0;
+        for (int g0 = 0; g0 < B; g0 += dec_group, groups++) {
+            const int nb = std::min(dec_group, B - g0);
+            MimiWs wg;
+            MimiWs* w = &mw;
+            if (nb != mw.B) { mimi_setup(m, wg, nb, T); w = &wg; }   // the last, smaller group: its own layout inside the same (grow-only) buffer
+            if (g0 > 0) w->zeroed = false;                           // (a group's history rows: zeroed again in front of its decode)
+            bool used = false;
+            mimi_range(m, *w, b.latents.as<float>() + (int64_t)g0 * lstride, lstride, f_done, f1, pcm.as<float>() + (size_t)g0 * T * spf, nullptr, m.stream2,
+                       (f_done == 0 && pcm_rows) ? pcm_rows + g0 : nullptr, &used);
+            direct += used ? 1 : 0;
+        }
+        if (direct != 0 && direct != groups) throw Error(PTTS_EINVAL, "ptts-hip: internal: the decoder's groups disagree about the direct PCM rows");
+        if (rows_used) *rows_used = direct != 0;
         f_done = f1;
     };
     auto emit_upto = [&](int f1) {   // hand frames [f_emitted, f1) to the streaming callbacks (they are decoded: f1 <= f_done)

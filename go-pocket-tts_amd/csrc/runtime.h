@@ -118,7 +118,7 @@ struct Batch {
     // the flow net's residual blocks as one launch (flow_cluster.hip): granule buffers and the tag / fault words; fc_ok: the model's shapes take it
     DevBuf fc_xbuf, fc_sync, fc_stamps;   // (fc_stamps: PTTS_FC_STAMPS measurement runs only)
     bool fc_ok = false;
-    unsigned* fc_fault() const { return fc_sync.as<unsigned>() + 32 * 8; }
+    unsigned* fc_fault() const { return fc_sync.as<unsigned>() + 32 * kFlowClusterMaxTiles; }
     int par = 0;
     float* fx_now() const { return (par ? fx2 : fx).as<float>(); }
     float* cur_now() const { return (par ? cur2 : cur).as<float>(); }
@@ -173,6 +173,7 @@ struct MimiWs {
     float *u[3] = {nullptr, nullptr, nullptr}, *uo[3] = {nullptr, nullptr, nullptr}, *h[3] = {nullptr, nullptr, nullptr};
     bool zeroed = false;
 };
+constexpr int kMimiGroup = 64;   // utterances decoded together through one decoder workspace (generate: larger batches go group after group)
 void mimi_setup(Model& m, MimiWs& w, int B, int T);
 // pcm_rows (device array of B PcmRow, whole range only): the fused final block writes every utterance's samples straight to its
 // row (page-locked host memory) instead of pcm; *rows_used says whether that path was taken (false: pcm holds the samples)

@@ -10,7 +10,7 @@
 namespace ptts {
 
 // ------------------------------------------------------------------------------------------------
-// Weight-streaming linear for the AR step (K2-K4, K8, K9, K11 at M = batch <= 64 rows).
+// Weight-streaming linear for the AR step (K2-K4, K8, K9, K11 at M = batch <= kStepMaxRows rows: one 16-row tile per blockIdx.y).
 //
 // The step is bound by streaming every weight once per step and, at these sizes (2-8 MB per
 // matrix over 256 CUs), by latency: a block gets one shot at the memory system, and every instruction it executes
@@ -74,7 +74,7 @@ constexpr int PRO_LN = 1, PRO_AFFINE = 2, PRO_MOD = 4, PRO_PARTIAL = 8, PRO_ONE 
 template <int WT, bool STAMP, int PRO, int NJ, int CG, bool FIN = false, bool CHAIN = false>
 __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* p_a, int p_lda, int p_ms, int p_n, int p_k, const float* p_part, const float* p_lnw,
                                                  const float* p_lnb, GemmArgs a, SkinnyFuse fu, float* partial, unsigned long long* stamps) {
-    // The nine leading scalars -- copies of a.Wt, a.A, a.amap.ld, a.M | split << 8, a.N, a.K, fu.partial, fu.ln_w, fu.ln_b: 14 dwords, all
+    // The nine leading scalars -- copies of a.Wt, a.A, a.amap.ld, a.M | split << 16, a.N, a.K, fu.partial, fu.ln_w, fu.ln_b: 14 dwords, all
     // the user SGPRs a kernel can have preloaded (-amdgpu-kernarg-preload-count) -- arrive in registers with the dispatch, so every
     // request on the critical path of the launch leaves before the first scalar-cache round trip for the argument block has
     // returned (that block is cold on every dispatch: ~0.5-1 us).
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
     // the whole prologue (sum, LayerNorm, hi/lo split, LDS image, the block's barrier) then runs while the weights stream, and each
     // wave starts multiplying when its own weights arrive.  (Round 2 had the weights first: in-situ stamps showed every wave's
     // prologue starting only when its weights were in, profiles/r3_step_stamps_weights_first.txt.)
-    const int p_m = p_ms & 0xff, splitk = p_ms >> 8;
+    const int p_m = p_ms & 0xffff, splitk = p_ms >> 16;
     // stamps (tools/microbench.py only; null in the product): shader-clock ticks of wave 0 of every block at the phase boundaries
 #define SK_STAMP(i) do { if (STAMP && threadIdx.x == 0) stamps[((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = (i) == 7 ? __builtin_amdgcn_s_memrealtime() : __builtin_amdgcn_s_memtime(); } while (0)
     SK_STAMP(0);
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(1024) void k_skinny(const void* p_wt, const float* 
 bool skinny_supported(const GemmArgs& a, int splitk) {
     if (splitk < 1) splitk = 1;
     const int kslice = splitk > 1 ? ((a.K + splitk - 1) / splitk + 127) / 128 * 128 : a.K;
-    return a.Wt && a.M <= 64 && a.K % 8 == 0 && kslice <= (splitk > 1 && (a.w_bf16 || a.wt_i8) ? SK_KMAX2 : SK_KMAX) && (!a.wt_i8 || a.wscale) && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
+    return a.Wt && a.M <= kStepMaxRows && a.K % 8 == 0 && kslice <= (splitk > 1 && (a.w_bf16 || a.wt_i8) ? SK_KMAX2 : SK_KMAX) && (!a.wt_i8 || a.wscale) && a.amap.rows_per_batch == 0 && a.cmap.rows_per_batch == 0 &&
            a.amap.ld % 4 == 0 && aligned16(a.A) && aligned16(a.W) && a.ldw % 8 == 0 && a.aop == AOP_NONE;
 }
 
@@ -604,16 +604,16 @@ static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
             grid.x = SK_CHAIN_BX;
             if (g_skinny_ev[0])
                 hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld,
-                                      a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
-            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
+                                      a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
+            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
                                     (unsigned long long*)nullptr);
             return;
         }
         if (fu.fin) {   // the flow net's final layer with the step's bookkeeping in its epilogue (one column block: grid.x == 1)
             if (g_skinny_ev[0])
                 hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld,
-                                      a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
-            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
+                                      a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
+            else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG, true>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
                                     (unsigned long long*)nullptr);
             return;
         }
@@ -621,18 +621,18 @@ static void launch_cg(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float
     if (SkinnyStampLog* lg = g_skinny_stamp_log) {
         const size_t blocks = (size_t)grid.x * grid.y * grid.z;
         if (lg->used_blocks + blocks <= lg->cap_blocks) {
-            hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
+            hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial,
                                lg->base + 8 * lg->used_blocks);
             lg->used_blocks += blocks;
             lg->desc.push_back(SkinnyStampLog::Desc{a.M, a.N, a.K, PRO, NJ, CG, (int32_t)blocks, splitk});
             return;
         }
     }
-    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, g_skinny_stamps);
+    if (g_skinny_stamps) hipLaunchKernelGGL((k_skinny<WBF16, true, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, g_skinny_stamps);
     else if (g_skinny_ev[0])   // hipExtLaunchKernel stamps the dispatch itself: the same interval rocprofv3 reports for the kernel
-        hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N,
+        hipExtLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, g_skinny_ev[0], g_skinny_ev[1], 0, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 16), a.N,
                               a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
-    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 8), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
+    else hipLaunchKernelGGL((k_skinny<WBF16, false, PRO, NJ, CG>), grid, dim3(1024), 0, stream, a.Wt, a.A, (int)a.amap.ld, a.M | (splitk << 16), a.N, a.K, fu.partial, fu.ln_w, fu.ln_b, a, fu, partial, (unsigned long long*)nullptr);
 }
 
 template <int WBF16, int PRO, int NJ>

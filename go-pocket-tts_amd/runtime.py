@@ -98,7 +98,7 @@ ABI_SYMBOLS = [
     "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
     "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
-    "ptts_model_share", "ptts_model_set_use_graph", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
+    "ptts_model_share", "ptts_model_set_use_graph", "ptts_model_set_max_batch", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
     "ptts_tokenizer_open", "ptts_tokenizer_open_bytes", "ptts_tokenizer_free", "ptts_tokenizer_vocab_size", "ptts_tokenizer_encode",
     "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast", "ptts_dsp_apply",
@@ -349,6 +349,11 @@ class Model:
         """ptts_opts.use_graph of an open model: hipGraph replay of the AR step (True) or plain launches (False)."""
         lib().ptts_model_set_use_graph.argtypes = [C.c_void_p, C.c_int32]
         _check(lib().ptts_model_set_use_graph(self.h, 1 if on else 0))
+
+    def set_max_batch(self, n: int):
+        """ptts_opts.max_batch of an open model / engine (1..256): utterances of one call that are stepped together."""
+        lib().ptts_model_set_max_batch.argtypes = [C.c_void_p, C.c_int32]
+        _check(lib().ptts_model_set_max_batch(self.h, int(n)))
 
     def share(self) -> "Model":
         """A second engine over this model's weights (own streams, KV caches, workspaces); this model must outlive it."""

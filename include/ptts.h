@@ -58,7 +58,7 @@ typedef struct ptts_opts {
     int32_t device;          /* HIP device ordinal */
     int32_t weights;         /* PTTS_WEIGHTS_* */
     int32_t kv;              /* PTTS_KV_* */
-    int32_t max_batch;       /* utterances stepped together on the GPU (default 64) */
+    int32_t max_batch;       /* utterances stepped together on the GPU (default 64, at most 256) */
     int32_t use_graph;       /* 0 (default): the ~47 launches of an AR step are issued per step -- the host stays ~3x ahead of
                                 the GPU and there is no gap between steps; 1: the step is captured once into a hipGraph and
                                 replayed (one host call per step, ~8 us of idle GPU between replays: up to 3 % slower, but the
@@ -170,6 +170,10 @@ typedef struct ptts_result {
 int  ptts_model_share(ptts_model* base, ptts_model** out);
 /* ptts_opts.use_graph of an open model, changed between calls (A/B measurement, hosts that become short of CPU) */
 int  ptts_model_set_use_graph(ptts_model* m, int32_t use_graph);
+/* ptts_opts.max_batch of an open model or engine (1..256), changed between calls: how many utterances of one ptts_generate call are stepped
+ * together (the reference's counterpart is its worker count, internal/server/server.go:132-134, internal/config/config.go:87); the engine's
+ * KV caches and workspaces follow on the next call */
+int  ptts_model_set_max_batch(ptts_model* m, int32_t max_batch);
 
 /* n_reqs == 1 reproduces GenerateAudio exactly.  n_reqs > 1 is this library's batching
  * extension: independent utterance chunks stepped together (per-row EOS countdown, ragged KV). */
