@@ -33,7 +33,7 @@ namespace ptts {
 
 namespace {
 // The pacing below was swept on one MI355X at 128 clients, utterances of 2-12 s (profiles/r4_serve_sweep.txt; tools/gpu_cont_trace.sh):
-constexpr int kDecoderCUs = 128;      // CUs open to the decoder's stream (of 256): see cont_create
+constexpr int kDecoderShare = 2;      // the decoder's stream gets 1 / kDecoderShare of the device's CUs (128 of the MI355X's 256): see cont_create
 constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
 constexpr int kDecodeMaxAge = 8;      // ... or the oldest has waited this many groups of steps (a caller waiting for audio is a caller not sending its next request)
 constexpr int kBandFrames = 16, kBandPercent = 16;   // a decode pads everything to its longest member: members within max(16 frames, 16 %) of it
@@ -45,9 +45,19 @@ hipStream_t decoder_stream_acquire(int device) {
     std::lock_guard<std::mutex> lock(g_dec_mu);
     auto& ent = g_dec_streams[device];
     if (!ent.first) {
-        uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < kDecoderCUs; i++) mask[i >> 5] |= 1u << (i & 31);
-        PTTS_HIP(hipExtStreamCreateWithCUMask(&ent.first, 8, mask));
+        // the mask follows the device: its CU count from the properties (bit i = CU i in the runtime's enumeration, which deals CUs round the XCDs, so the
+        // low half of the bits is half of every XCD), and the stream is created on THAT device whatever the calling thread's current one is
+        int cus = 0, cur = 0;
+        PTTS_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+        if (cus <= 0) throw Error(PTTS_ENODEVICE, "ptts-hip: device reports no compute units");
+        PTTS_HIP(hipGetDevice(&cur));
+        if (cur != device) PTTS_HIP(hipSetDevice(device));
+        std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+        const int open = std::max(1, cus / kDecoderShare);
+        for (int i = 0; i < open; i++) mask[(size_t)i >> 5] |= 1u << (i & 31);
+        const hipError_t e = hipExtStreamCreateWithCUMask(&ent.first, (uint32_t)mask.size(), mask.data());
+        if (cur != device) (void)hipSetDevice(cur);
+        if (e != hipSuccess) { ent.first = nullptr; g_dec_streams.erase(device); throw Error(PTTS_ENODEVICE, strfmt("hip: hipExtStreamCreateWithCUMask failed: %s", hipGetErrorString(e))); }
     }
     ent.second++;
     return ent.first;
@@ -57,7 +67,8 @@ void decoder_stream_release(int device) {
     auto it = g_dec_streams.find(device);
     if (it == g_dec_streams.end()) return;
     if (--it->second.second <= 0) { (void)hipStreamDestroy(it->second.first); g_dec_streams.erase(it); }
-}constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
+}
+constexpr int kFramesPerDecode = 3072;   // frames (utterances x longest) one Mimi decode of finished slots may take: bounds its workspace (~2.7 MB of activations per frame)
 }
 
 struct ContEngine {

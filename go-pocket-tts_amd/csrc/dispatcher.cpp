@@ -267,6 +267,22 @@ void Dispatcher::run_continuous(int w) {
                     d->cv.notify_one();
                 }
             }
+        } catch (const FlowClusterFault&) {
+            // a hand-off inside k_flow_cluster timed out (its workgroups were not running together): nobody is failed.  Everything in flight goes back to the
+            // head of the queue with a clean result, the engine is rebuilt -- on the 2 x depth launches from now on (Model::fc_disabled), which compute the
+            // same bits -- and the utterances start over.  Counted in ptts_dispatch_stats.flow_cluster_fallbacks.
+            std::vector<void*> tags;
+            for (DispatchItem* d : take) tags.push_back(d);
+            if (eng) cont_abort(*eng, PTTS_ENODEVICE, tags);
+            eng.reset();
+            std::lock_guard<std::mutex> lock(mu);
+            for (auto it = tags.rbegin(); it != tags.rend(); ++it) {
+                DispatchItem* d = static_cast<DispatchItem*>(*it);
+                ptts_free_result(d->res);
+                std::memset(d->res, 0, sizeof *d->res);
+                d->res->eos_step = -1;
+                queue.push_front(d);
+            }
         } catch (const std::exception& ex) {   // a HIP error or a malformed request that slipped through: everyone in flight is told, the engine is rebuilt
             const Error* pe = dynamic_cast<const Error*>(&ex);
             const int code = pe ? pe->code : PTTS_EINVAL;
@@ -361,6 +377,7 @@ void dispatcher_stats(Dispatcher* d, ptts_dispatch_stats* out) {
     out->mean_wait_us = d->n_requests ? d->sum_wait_us / (double)d->n_requests : 0.0;
     out->cont_steps = d->cont_steps; out->cont_slot_steps = d->cont_slot_steps;
     out->mean_exec_us = d->n_batches ? d->sum_exec_us / (double)d->n_batches : 0.0;
+    for (Model* m : d->models) out->flow_cluster_fallbacks += m->fc_fallbacks.load();
 }
 
 }  // namespace ptts

@@ -181,16 +181,13 @@ __device__ __forceinline__ void ff_gemm1(const char* w1, int r16, int q, const F
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // READS OF THE SUMS MUST STAY AWAY FROM THE TAIL OF THE CHAIN.  Found with tools/probes/rowlin_debug.py: k_mimi_rowlin's first cut was bit-equal to the
-    // unfused path everywhere except ONE output column of the FIRST chunk in waves 1..3 -- element 2 of one accumulator tile, lanes 48..63, missing the
-    // last product's contribution; deterministic run to run.  That was the only place where hipcc had hoisted the v_accvgpr_read of a finished tile to right
-    // behind its last v_mfma_f32_16x16x32_bf16 (one more matrix instruction and `s_nop 6` between them, the compiler's own hazard count); everywhere else a
-    // barrier and hundreds of cycles lay between.  32 idle cycles here fixed waves 1 and 2, not wave 3; tying every reader to a point well behind the chain
-    // (the empty asm statements with the sums as operands: here, in k_mimi_rowlin's store_piece, behind k_mimi_ffn's barrier) fixed all of them, and the
-    // op-level tests (tests/test_gpu_mimi_transformer.py::test_layer_piece_*) hold the kernels against the oracle at every row-count class.  Whether
-    // the cause is a short hazard count for this gfx950 instruction in ROCm 7.2's hipcc or something this kernel's inline assembly provokes is not
-    // established; round 2's k_gemm4 died of the same signature (one accumulator-derived register, lanes 48..63, right behind the K loop: tools/probes/gemm4).
-    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[0]), "+a"(acc[1]));   // (the sums as operands: no read of them can be scheduled in front of the idle cycles)
+    // (Round 4 fenced the end of this chain with 32 idle states and tied every reader of the sums to a later point, after k_mimi_rowlin's first cut had returned
+    // one output column -- lanes 48..63 of one register -- without a product.  Round 5 found the cause with the failing cut rebuilt and bisected in its ISA
+    // (tools/probes/mfma_hazard/README.md): not the accumulators at all, but the RoPE rotation behind them -- hipcc's SLP vectoriser had packed v[2] * c.y into
+    // `v_pk_mul_f32 ... op_sel:[0,1]`, the scheduler had put the next matrix instruction right behind it, and on gfx950 a packed-f32 op whose low result mixes the
+    // dword halves of its sources returns a wrong low result in its last pass (lanes 48..63) when it is issued in the shadow of one MFMA and followed at once by
+    // another.  This file is therefore compiled with -fno-slp-vectorize (Makefile), tools/isa_hazard_check.py scans every shipped code object for the pattern
+    // (tests/test_isa_hazards.py), and the idle states are gone.)
 }
 
 }  // namespace

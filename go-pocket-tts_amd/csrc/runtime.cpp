@@ -205,6 +205,7 @@ Batch::~Batch() {
 }
 
 static bool open_linears(Batch& b, StepOpenLinears& lin);
+static bool step_flow(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain);
 
 Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     if (n_slots <= 0) throw Error(PTTS_EINVAL, "ptts-hip: batch needs at least one slot");
@@ -261,7 +262,7 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
     {   // flow_cluster.hip: bf16 step copies of every residual block's linears, the width it is built for
         const char* sw = getenv("PTTS_FLOW_CLUSTER");   // A/B switch, read per batch: 0 = the 2 x depth launches (tests compare the two forms bit for bit)
         const bool off = sw && sw[0] == '0';
-        bool ok = !off && d.flow_dim == 512 && d.flow_depth > 0 && d.flow_depth <= FC_MAX_DEPTH && n_slots <= kStepMaxRows &&
+        bool ok = !off && !m.fc_disabled.load() && d.flow_dim == 512 && d.flow_depth > 0 && d.flow_depth <= FC_MAX_DEPTH && n_slots <= kStepMaxRows &&
                   flow_cluster_fits(n_slots, m.device);   // (every workgroup of the grid resident at once: its hand-offs spin on its peers)
         for (int r = 0; ok && r < d.flow_depth; r++) {
             const auto& rb = d.rb[r];
@@ -637,15 +638,26 @@ static bool open_linears(Batch& b, StepOpenLinears& lin) {
     return true;
 }
 
-// a hand-off inside k_flow_cluster gave up (flow_cluster.hip: bounded sweeps): the frames of this call are not to be trusted.  The exchange state is
-// cleared so that the next call starts clean, and the call fails.
-void flow_cluster_fault(Batch& b) {
+// a hand-off inside k_flow_cluster gave up (flow_cluster.hip: bounded sweeps -- a tile's eight workgroups were not all running: another tenant on the CUs, a
+// masked queue): the frames computed since are not to be trusted.  The exchange state is cleared, the batch -- and whatever batch this engine builds
+// later -- goes back to the 2 x depth launches, which compute the same bits, and the event is counted (ptts_dispatch_stats.flow_cluster_fallbacks).
+void flow_cluster_recover(Batch& b) {
     hipStream_t s = b.m->stream;
     (void)hipStreamSynchronize(s);
     (void)hipMemsetAsync(b.fc_xbuf.p, 0, flow_cluster_xbuf_bytes(b.B), s);
     (void)hipMemsetAsync(b.fc_sync.p, 0, kFlowClusterSyncBytes, s);
     (void)hipStreamSynchronize(s);
-    throw Error(PTTS_ENODEVICE, "ptts-hip: the flow net's in-launch hand-off timed out (k_flow_cluster); the batch's frames were discarded");
+    b.fc_ok = false;
+    // (the captured step graphs hold the cluster launch: drop them, the next replay captures the launches)
+    for (auto& set : b.graphs) for (auto& row : set) for (hipGraphExec_t& g : row) if (g) { (void)hipGraphExecDestroy(g); g = nullptr; }
+    for (auto& gs : b.graph_steps) gs[0] = gs[1] = 0;
+    b.opened = false;
+    b.m->fc_disabled.store(true);
+    b.m->fc_fallbacks.fetch_add(1);
+}
+void flow_cluster_fault(Batch& b) {
+    flow_cluster_recover(b);
+    throw FlowClusterFault(PTTS_ENODEVICE, "ptts-hip: the flow net's in-launch hand-off timed out (k_flow_cluster); the steps concerned are re-issued as launches");
 }
 
 void step_open(Batch& b) {
@@ -764,7 +776,24 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
             step_gemm(m, mk(m, last, flat(D), d.out_eos, b.eos.as<float>(), flat(1), B));
         }
     }
-    // LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step
+    b.tail_fused = tail_fused;
+    finished = step_flow(b, lsd, opened, fuse_finish, chain);
+    if (!b.capturing) b.kv_bound++;   // every live slot has appended one key
+    return finished;
+}
+
+// LSDDecode (flow_lm.go:311-353) with flowNet.Forward (flow_net.go:314-356) per Euler step: the flow part of a step, from `last` (out_norm's rows), `sy`
+// (when the transformer's last launch produced it: Batch::tail_fused) and `cur` (x0 -> the frame)
+static bool step_flow(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
+    bool finished = false;
+    Model& m = *b.m;
+    const Desc& d = m.d;
+    const int B = b.B, D = d.d_model, C = d.flow_dim, NA = d.ada_all.out;
+    hipStream_t s = m.stream;
+    const bool tail_fused = b.tail_fused;
+    float* last = b.last.as<float>();
+    float* sy = b.sy.as<float>();
+    const float* tc = m.tcomb.at(lsd)->as<float>();
     float* ada = b.ada.as<float>();
     float* fx = b.fx_now();
     float* fh2 = b.fh2.as<float>();
@@ -821,8 +850,12 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
         finished = step_fused_linear(b, fx, fin, d.final_linear, cur, d.ldim, B, EPI_AXPY, nullptr, cur, 1.0f / (float)lsd, nullptr, &chained);  // current += flow / steps
         if (chained) { b.opened = true; b.par ^= 1; }
     }
-    if (!b.capturing) b.kv_bound++;   // every live slot has appended one key
     return finished;
+}
+
+void step_flow_again(Batch& b, int lsd) {
+    b.opened = false; b.par = 0;
+    (void)step_flow(b, lsd, false, false, false);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1682,7 +1715,18 @@ void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res) {
         for (size_t o = 0; o < all.size(); o += (size_t)mb) {
             std::vector<int> idx(all.begin() + (long)o, all.begin() + (long)std::min(all.size(), o + (size_t)mb));
             try {
-                generate_chunk(m, reqs, idx, res, kv.first);
+                try {
+                    generate_chunk(m, reqs, idx, res, kv.first);
+                } catch (const FlowClusterFault&) {
+                    // a hand-off inside k_flow_cluster timed out somewhere in this chunk's AR loop (found when the loop's counters were read back).  The chunk's
+                    // inputs are the requests themselves: run it again on the 2 x depth launches, which compute the same bits (the batch has been switched
+                    // over: flow_cluster_recover).  Only a chunk that has already spoken to its caller -- step callbacks, streamed samples -- cannot be re-run.
+                    bool spoke = false;
+                    for (int i : idx) spoke |= reqs[i].step_callback != nullptr || reqs[i].pcm_callback != nullptr;
+                    if (spoke) throw;
+                    for (int i : idx) { ptts_free_result(&res[i]); std::memset(&res[i], 0, sizeof res[i]); res[i].eos_step = -1; }
+                    generate_chunk(m, reqs, idx, res, kv.first);
+                }
             } catch (const Error& e) {
                 for (int i : idx) { ptts_free_result(&res[i]); res[i].status = e.code; res[i].eos_step = -1; }
                 if (first_err.empty()) first_err = e.what();

@@ -2,6 +2,7 @@
 // prefill, AR step (hipGraph), Mimi decode, GenerateAudio loop.
 #pragma once
 
+#include <atomic>
 #include <functional>
 
 #include "kernels.h"
@@ -65,6 +66,10 @@ struct Model {
     std::unique_ptr<Batch> cached_batch;
     Prof prof;
     int fc_inject = 0;   // test hook: the next k_flow_cluster launch (plain launches) runs with FlowClusterArgs::inject = this, once
+    // k_flow_cluster's bounded hand-offs gave up (a tile's workgroups were not running together: a masked or shared device): the steps concerned were
+    // re-issued as the 2 x depth launches (same bits) -- fc_fallbacks counts the events -- and this engine's batches keep the launches from then on
+    std::atomic<int64_t> fc_fallbacks{0};
+    std::atomic<bool> fc_disabled{false};
 
     ~Model();
     template <class T> const T* at(size_t off) const { return off == NONE ? nullptr : reinterpret_cast<const T*>(arena + off); }
@@ -118,6 +123,7 @@ struct Batch {
     // the flow net's residual blocks as one launch (flow_cluster.hip): granule buffers and the tag / fault words; fc_ok: the model's shapes take it
     DevBuf fc_xbuf, fc_sync, fc_stamps;   // (fc_stamps: PTTS_FC_STAMPS measurement runs only)
     bool fc_ok = false;
+    bool tail_fused = false;   // the step's last transformer launch also produced sy (silu(t + cond_embed)): the flow part can be re-issued from `last` / `sy` / `cur` as they stand
     unsigned* fc_fault() const { return fc_sync.as<unsigned>() + 32 * kFlowClusterMaxTiles; }
     int par = 0;
     float* fx_now() const { return (par ? fx2 : fx).as<float>(); }
@@ -194,7 +200,14 @@ void batch_prompt(Batch& b, const float* rows_dev, const int64_t* row_offsets);
 // chain (with fuse_finish): the last launch also opens the next step (sets b.opened); the frame then lives in the latents only, b.cur holds the next x0
 bool step_core(Batch& b, int lsd_steps, bool opened = false, bool fuse_finish = false, bool chain = false);
 void step_open(Batch& b);
-void flow_cluster_fault(Batch& b);   // throws (after clearing the exchange state)                                       // first launch of a generate step (input, noise, the two 32-wide linears)
+// A hand-off inside k_flow_cluster timed out (the fault word of the batch is set).  flow_cluster_recover clears the exchange state, switches the batch (and
+// the engine's later batches) to the 2 x depth launches and counts the event; flow_cluster_fault does that and throws FlowClusterFault: the caller owns a
+// retry -- generate() runs the chunk again on the launches, the staged step re-issues its flow part, the dispatcher re-queues what was in flight.
+struct FlowClusterFault : Error { using Error::Error; };
+void flow_cluster_recover(Batch& b);
+void flow_cluster_fault(Batch& b);
+void step_flow_again(Batch& b, int lsd_steps);   // the LSD decode of the step just taken, once more, from the intact `last` / `sy` and the caller-restored `cur` (staged API)
+                                    // first launch of a generate step (input, noise, the two 32-wide linears)
 // xformer_out (optional, staged parity checks): the decoder transformer's output rows [B][T * up_stride][mimi_dim]
 void mimi_decode(Model& m, const float* lat_dev, int64_t lat_bstride, int B, int T, float* pcm_dev, float* mimi_latent_dev, float* xformer_out = nullptr);
 // pieces of the generate loop that the continuous batch (continuous.cpp) reuses

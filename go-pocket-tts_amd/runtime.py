@@ -87,16 +87,15 @@ class _VoiceTensor(C.Structure):   # ptts_voice_tensor
 
 _lib = None
 
-# every symbol include/ptts.h declares (tests check that the built library exports all of them)
+# every symbol include/ptts.h declares (tests check that the built library exports all of them -- and none of HOOK_SYMBOLS)
 ABI_SYMBOLS = [
     "ptts_default_opts", "ptts_model_open", "ptts_model_open_bytes", "ptts_model_close", "ptts_model_info", "ptts_last_error",
     "ptts_plan_create", "ptts_plan_create_bytes", "ptts_plan_arena_bytes", "ptts_model_open_planned", "ptts_plan_free",
     "ptts_generate", "ptts_free_result", "ptts_text_embeddings", "ptts_batch_new", "ptts_batch_free", "ptts_batch_reset",
     "ptts_batch_set_voice_state", "ptts_batch_prompt", "ptts_batch_step", "ptts_batch_offsets", "ptts_batch_read_kv",
-    "ptts_decode_latents", "ptts_decode_stages", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_debug_flow_cluster_inject", "ptts_noise_rows", "ptts_speaker_project", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
+    "ptts_decode_latents", "ptts_noise_rows", "ptts_speaker_project", "ptts_flow_direction", "ptts_op_linear", "ptts_op_layernorm", "ptts_op_rope",
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
-    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
-    "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
+        "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
     "ptts_model_share", "ptts_model_set_use_graph", "ptts_model_set_max_batch", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
@@ -104,7 +103,11 @@ ABI_SYMBOLS = [
     "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast", "ptts_dsp_apply",
     "ptts_voice_file_open", "ptts_voice_file_open_bytes", "ptts_voice_file_close", "ptts_voice_file_kind", "ptts_voice_file_embedding",
     "ptts_voice_file_modules", "ptts_voice_file_module", "ptts_voice_file_state", "ptts_voice_open", "ptts_voice_open_bytes",
-    "ptts_mimi_layer_piece",
+    ]
+# the test / measurement hooks of include/ptts_debug.h: exported by libptts_hooks.so, never by libptts_hip.so (checked by __graft_entry__.build())
+HOOK_SYMBOLS = [
+    "ptts_decode_stages", "ptts_mimi_layer_piece", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_debug_flow_cluster_inject",
+    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
 ]
 
 
@@ -157,11 +160,7 @@ def lib():
         L.ptts_batch_offsets.argtypes = [C.c_void_p, _IP]
         L.ptts_batch_read_kv.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, _FP]
         L.ptts_decode_latents.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP]
-        L.ptts_decode_stages.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP, _FP]
         L.ptts_noise_rows.argtypes = [C.c_void_p, C.c_uint64, C.c_float, C.c_int32, _FP]
-        L.ptts_debug_last_attention_kernel.restype = C.c_char_p
-        L.ptts_debug_launch_counts.restype = C.c_int64
-        L.ptts_debug_launch_counts.argtypes = [C.c_int32, C.c_char_p, C.c_int64]
         L.ptts_flow_direction.argtypes = [C.c_void_p, _FP, C.c_float, C.c_float, _FP, C.c_int32, _FP]
         L.ptts_voice_create.argtypes = [C.c_void_p, C.POINTER(_FP), _IP, _IP, C.POINTER(C.c_void_p)]
         L.ptts_voice_free.argtypes = [C.c_void_p]
@@ -177,8 +176,6 @@ def lib():
         L.ptts_voice_file_state.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_FP), _IP, _IP]
         L.ptts_voice_open.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p)]
         L.ptts_voice_open_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
-        L.ptts_mimi_layer_piece.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int32, _FP]
-        L.ptts_debug_flow_cluster_inject.argtypes = [C.c_void_p, C.c_int32]
         L.ptts_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.ptts_profile_read.argtypes = [C.c_void_p, C.POINTER(_Profile)]
         L.ptts_op_linear.argtypes = [_FP, _FP, _FP, C.c_int64, C.c_int64, C.c_int64, _FP]
@@ -189,6 +186,29 @@ def lib():
         L.ptts_op_convtr1d_righttrim.argtypes = [_FP, _FP, _FP] + [C.c_int64] * 7 + [_FP]
         _lib = L
     return _lib
+
+
+HOOKS_PATH = os.path.join(_HERE, "libptts_hooks.so")   # (also beside another build of the product library named by PTTS_LIB_PATH: it binds to the libptts_hip.so SONAME already loaded)
+_hooks = None
+
+
+def hooks():
+    """libptts_hooks.so: the entry points of include/ptts_debug.h (launch census, staged decoder observation points, in-kernel stamps, micro-benchmarks,
+    fault injection).  Loaded beside the product library by tests and tools only; it resolves its internals against the libptts_hip.so already mapped."""
+    global _hooks
+    if _hooks is None:
+        lib()   # the product library first: the hooks' DT_NEEDED libptts_hip.so then resolves to the copy already in the process
+        if not os.path.exists(HOOKS_PATH):
+            raise PttsError(PTTS_ENODEVICE, f"{HOOKS_PATH} is missing: run __graft_entry__.build()")
+        H = C.CDLL(HOOKS_PATH, mode=C.RTLD_GLOBAL)
+        H.ptts_decode_stages.argtypes = [C.c_void_p, _FP, C.c_int32, C.c_int32, _FP, _FP, _FP]
+        H.ptts_debug_last_attention_kernel.restype = C.c_char_p
+        H.ptts_debug_launch_counts.restype = C.c_int64
+        H.ptts_debug_launch_counts.argtypes = [C.c_int32, C.c_char_p, C.c_int64]
+        H.ptts_mimi_layer_piece.argtypes = [C.c_void_p, C.c_int32, C.c_int32, _FP, C.c_int64, C.c_int32, C.c_int32, _FP]
+        H.ptts_debug_flow_cluster_inject.argtypes = [C.c_void_p, C.c_int32]
+        _hooks = H
+    return _hooks
 
 
 def _check(rc: int):
@@ -393,18 +413,18 @@ class Model:
         """norm1 -> in_proj -> RoPE(q, k) of Mimi decoder-transformer layer `layer` on rows x [R, 512] -> [R, 1536] (ptts_mimi_layer_piece)."""
         x = _f32(x)
         out = np.empty((x.shape[0], 3 * x.shape[1]), np.float32)
-        _check(lib().ptts_mimi_layer_piece(self.h, layer, 0, _fp(x), x.shape[0], pos0, rows_per_seg, _fp(out)))
+        _check(hooks().ptts_mimi_layer_piece(self.h, layer, 0, _fp(x), x.shape[0], pos0, rows_per_seg, _fp(out)))
         return out
 
     def debug_flow_cluster_inject(self, block: int) -> None:
         """Test hook: the next plain-launched AR step's k_flow_cluster runs with one workgroup withholding its publish for flow-net block `block` (1-based)."""
-        _check(lib().ptts_debug_flow_cluster_inject(self.h, int(block)))
+        _check(hooks().ptts_debug_flow_cluster_inject(self.h, int(block)))
 
     def mimi_layer_ffn(self, layer: int, x) -> np.ndarray:
         """x + layer_scale_2 * linear2(gelu(linear1(norm2(x)))) of Mimi decoder-transformer layer `layer` on rows x [R, 512]."""
         x = _f32(x)
         out = np.empty_like(x)
-        _check(lib().ptts_mimi_layer_piece(self.h, layer, 1, _fp(x), x.shape[0], 0, 0, _fp(out)))
+        _check(hooks().ptts_mimi_layer_piece(self.h, layer, 1, _fp(x), x.shape[0], 0, 0, _fp(out)))
         return out
 
     def open_voice(self, src) -> "DeviceVoice":
@@ -452,7 +472,7 @@ class Model:
         pcm = np.empty((n, fr * self.info.samples_per_frame), np.float32)
         ml = np.empty((n, self.info.mimi_dim, fr), np.float32)
         xf = np.empty((n, fr * self.info.steps_per_latent, self.info.mimi_dim), np.float32)
-        _check(lib().ptts_decode_stages(self.h, _fp(lat), n, fr, _fp(pcm), _fp(ml), _fp(xf)))
+        _check(hooks().ptts_decode_stages(self.h, _fp(lat), n, fr, _fp(pcm), _fp(ml), _fp(xf)))
         return pcm, ml, xf
 
     def speaker_project(self, latent) -> np.ndarray:
@@ -841,13 +861,13 @@ def op_attention_positions(q, k, v, posq, posk, context: int) -> np.ndarray:
 
 def last_attention_kernel() -> str:
     """Which kernel this thread's last attention launch used (ptts_debug_last_attention_kernel)."""
-    return lib().ptts_debug_last_attention_kernel().decode()
+    return hooks().ptts_debug_last_attention_kernel().decode()
 
 
 def launch_counts(on: bool) -> dict:
     """Kernel launches noted on this thread since the previous call ({kernel: count}); switches the census on / off."""
     buf = C.create_string_buffer(4096)
-    lib().ptts_debug_launch_counts(1 if on else 0, buf, 4096)
+    hooks().ptts_debug_launch_counts(1 if on else 0, buf, 4096)
     return {k: int(v) for k, v in (item.split("=") for item in buf.value.decode().split(";") if item)}
 
 
@@ -895,7 +915,7 @@ class _DispatchOpts(C.Structure):
 
 class _DispatchStats(C.Structure):
     _fields_ = [("requests", C.c_int64), ("batches", C.c_int64), ("cancelled_waiting", C.c_int64), ("max_queue_depth", C.c_int64),
-                ("mean_batch", C.c_double), ("mean_wait_us", C.c_double), ("mean_exec_us", C.c_double), ("cont_steps", C.c_int64), ("cont_slot_steps", C.c_int64)]
+                ("mean_batch", C.c_double), ("mean_wait_us", C.c_double), ("mean_exec_us", C.c_double), ("cont_steps", C.c_int64), ("cont_slot_steps", C.c_int64), ("flow_cluster_fallbacks", C.c_int64)]
 
 
 DISPATCH_EXEC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.POINTER(_Request), C.c_int32, C.POINTER(_Result), C.c_void_p, C.c_int32)

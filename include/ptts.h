@@ -256,6 +256,8 @@ typedef struct ptts_dispatch_stats {
     int64_t requests, batches, cancelled_waiting, max_queue_depth;
     double  mean_batch, mean_wait_us, mean_exec_us;
     int64_t cont_steps, cont_slot_steps;   /* continuous batching: AR steps launched; utterances stepping in them, summed (ratio = mean occupied slots) */
+    int64_t flow_cluster_fallbacks;        /* times a hand-off inside k_flow_cluster timed out on one of the dispatcher's models: the steps concerned were redone as
+                                            * launches (same bits, nobody failed) and that engine keeps the launches from then on */
 } ptts_dispatch_stats;
 int  ptts_dispatcher_create(ptts_model* const* models, int32_t n_models, const ptts_dispatch_opts* opts, ptts_dispatcher** out);
 /* queueing logic over a caller-supplied executor (no GPU involved): unit tests of the coalescing / cancellation rules */
@@ -333,22 +335,10 @@ int  ptts_batch_step(ptts_batch* b, const float* frames_in, int32_t lsd_steps, c
                      float* frames_out, float* eos_logits, float* last_hidden);
 int  ptts_batch_offsets(ptts_batch* b, int64_t* out /* [n_slots] */);
 int  ptts_batch_read_kv(ptts_batch* b, int32_t slot, int32_t layer, float* k, float* v /* [H, offset, Dh] each */);
-/* Pieces of one Mimi decoder-transformer layer on host rows, through the kernels the decoder itself launches for them (staged parity checks of
- * mimiTransformerLayer, mimi.go:245-441).  which = PTTS_MIMI_PIECE_QKV: norm1 -> in_proj -> RoPE of q and k at positions pos0 + (row % rows_per_seg)
- * (rows_per_seg 0: pos0 + row): x [rows, mimi_dim] -> out [rows, 3 mimi_dim] (q | k | v).  which = PTTS_MIMI_PIECE_FFN: x + layer_scale_2 *
- * linear2(gelu(linear1(norm2(x)))): x [rows, mimi_dim] -> out [rows, mimi_dim]. */
-#define PTTS_MIMI_PIECE_QKV 0
-#define PTTS_MIMI_PIECE_FFN 1
-int  ptts_mimi_layer_piece(ptts_model* m, int32_t layer, int32_t which, const float* x, int64_t rows, int32_t pos0, int32_t rows_per_seg, float* out);
 /* Model.LatentToMimi + Model.MimiDecode: latents [n_utt, frames, ldim] host -> pcm [n_utt, frames*samples_per_frame] host;
  * mimi_latent (optional) receives LatentToMimi's [n_utt, mimi_dim, frames] */
 int  ptts_decode_latents(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,
                          float* pcm, float* mimi_latent);
-/* The same with one more observation point: transformer_out (optional) receives the decoder transformer's output, i.e. the
- * [n_utt, frames * steps_per_latent, mimi_dim] rows that MimiModel.DecodeFromLatent hands to the SEANet decoder after its
- * mimiTransformerLayer loop (mimi.go:733-748) -- the staged check of a17 (window attention, RoPE, layer_scale). */
-int  ptts_decode_stages(ptts_model* m, const float* latents, int32_t n_utt, int32_t frames,
-                        float* pcm, float* mimi_latent, float* transformer_out);
 /* Voice cloning, the part the reference holds natively: projectSpeakerConditioning
  * (internal/onnx/voice_encode.go:119-158) -- Mimi-encoder latents [frames, 512] (host) times flow_lm.speaker_proj_weight
  * [d_model, 512] -> voice embedding [frames, d_model] (host), which a request then carries as `voice_embedding`.  The Mimi encoder
@@ -376,35 +366,14 @@ int ptts_op_convtr1d_righttrim(const float* x /* [B,Cin,L] */, const float* w /*
                  int64_t b, int64_t cin, int64_t len, int64_t cout_per_group, int64_t k, int64_t stride, int64_t groups,
                  float* y /* [B,Cout,L*stride] */);                                                                                  /* ops.ConvTranspose1DRightTrim convtranspose1d.go:213 (k = 2*stride, trim k-stride; groups 1 or Cin) */
 
-/* build/version string, e.g. "ptts-hip 0.1 gfx950" */
-/* Kernel micro-benchmarks (tools/microbench.py; device-resident synthetic operands, HIP-event timing; not part of the
- * drop-in path).  ptts_debug_gemm also returns max |C_variant - C_other| between the two many-row GEMM kernels. */
-int ptts_debug_time_skinny(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, int32_t iters, float* avg_us);
-int ptts_debug_skinny_stamps(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t splitk, int32_t fuse_ln, uint64_t* out /* [max_blocks][8] */,
-                             int32_t max_blocks, int32_t* n_blocks);
-int ptts_debug_step_stamps(ptts_batch* b, int32_t lsd_steps, uint64_t* out /* [cap_blocks][8] */, int64_t cap_blocks, int32_t* desc /* [cap_desc][8] */,
-                           int32_t cap_desc, int32_t* n_desc);
-int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
-                    float* maxdiff);
 /* audio.WritePCM16Samples on the device (internal/audio/wav_stream.go:43-54), without the byte packing */
 int ptts_op_pcm16(const float* samples, int64_t n, int16_t* out);
 
-/* name of the kernel the calling thread's last attention launch used ("k_attn_step", "k_attn_window", "k_attn_window<ragged>",
- * "k_attention"): lets a parity test assert that it exercised the kernel it means to */
-const char* ptts_debug_last_attention_kernel(void);
-
-/* Launch census of the calling thread: writes "kernel=count;..." of the launches noted since the previous call (truncated to
- * cap - 1 characters, returns the full length), clears it, and switches counting on (1) or off (0) from here on.  Calls that
- * run their launches on the calling thread (every entry point except the dispatcher's) are covered. */
-int64_t ptts_debug_launch_counts(int32_t on, char* out, int64_t cap);
-
-/* Test hook for the bounded hand-offs of k_flow_cluster (csrc/flow_cluster.hip): the model's NEXT plain-launched AR step runs the flow net's residual
- * blocks with one workgroup withholding what it should publish for block `block` (1-based; 0 clears).  Its peers' sweeps give up after their bound, the
- * launch runs to its end, and the call that contained the step fails with PTTS_ENODEVICE ("hand-off timed out"); the exchange state is cleared, the next
- * call is clean.  Nothing in the product sets it. */
-int ptts_debug_flow_cluster_inject(ptts_model* m, int32_t block);
-
+/* build/version string, e.g. "ptts-hip 0.2 gfx950" */
 const char* ptts_version(void);
+
+/* Test and measurement hooks (launch census, in-kernel stamps, micro-benchmarks, staged observation points of the decoder, the fault injection of
+ * k_flow_cluster's hand-offs) are NOT in this library: they are declared in ptts_debug.h and live in libptts_hooks.so, which the tests load beside it. */
 
 #ifdef __cplusplus
 }

@@ -292,10 +292,10 @@ def test_full_size_64_slots_mixed_lengths_finite_eos_against_stand_alone_and_ora
     gm.close()
 
 
-def test_a_timed_out_hand_off_fails_the_requests_in_flight_and_the_engine_comes_back(pkg):
+def test_a_timed_out_hand_off_requeues_the_requests_in_flight_and_nobody_is_failed(pkg):
     """The continuous engine runs k_flow_cluster in every step at the b6369a24 shapes.  With one of its workgroups made to withhold a publish (test hook,
-    tests/test_gpu_flow_cluster.py) the engine's read-back carries the fault word: everyone in flight is answered with the hand-off error, the engine is
-    rebuilt, and the requests sent afterwards get their stand-alone audio."""
+    tests/test_gpu_flow_cluster.py) the engine's read-back carries the fault word: everything in flight goes back to the head of the queue, the engine is
+    rebuilt on the 2 x depth launches (same bits) and every caller gets its stand-alone audio; the event is counted in the dispatcher's stats."""
     import bench
     cfg = pkg.synth.SynthConfig.full()
     path = bench.checkpoint_path(pkg, "BF16", 0, lambda: None)
@@ -308,13 +308,15 @@ def test_a_timed_out_hand_off_fails_the_requests_in_flight_and_the_engine_comes_
     try:
         gm.debug_flow_cluster_inject(2)
         got, errs = run_clients(d, prompts, cfgs)
-        assert all(e is not None for e in errs), [type(e).__name__ if e else r.n_frames for e, r in zip(errs, got)]
-        assert any("hand-off timed out" in str(e) or "request failed" in str(e) for e in errs), [str(e) for e in errs]
+        assert all(e is None for e in errs), [str(e) for e in errs]
+        assert d.stats()["flow_cluster_fallbacks"] == 1
+        for i in range(6):
+            assert got[i].n_frames == want[i].n_frames
+            np.testing.assert_allclose(got[i].latents[:4], want[i].latents[:4], rtol=0, atol=2e-2 * float(np.abs(want[i].latents).max()))
         got, errs = run_clients(d, prompts, cfgs)
         assert all(e is None for e in errs), [str(e) for e in errs]
         for i in range(6):
             assert got[i].n_frames == want[i].n_frames
-            np.testing.assert_allclose(got[i].latents[:4], want[i].latents[:4], rtol=0, atol=2e-2 * float(np.abs(want[i].latents).max()))
     finally:
         d.close()
         dv.close()

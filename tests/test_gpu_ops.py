@@ -194,7 +194,7 @@ def test_weights_resident_gemm_equals_the_tile_gemm(pkg, shape):
     narrower N x K that is zero-padded in LDS."""
     import ctypes as C
     M, N, K, epi = shape
-    L = pkg.runtime.lib()
+    L = pkg.runtime.hooks()
     L.ptts_debug_gemm.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 2
     us, md = C.c_float(0), C.c_float(-1)
     rc = L.ptts_debug_gemm(M, N, K, 1, 40, epi, 1, C.byref(us), C.byref(md))
@@ -215,7 +215,7 @@ def test_many_row_gemm5_equals_gemm3_bit_for_bit_and_itself_run_to_run(pkg, shap
     single weight chunk (K = 64), split-K in 1024-deep slices (the prefill's linear2: raw sums per plane).  The debug entry also runs the variant three more times and compares bits (a race would show)."""
     import ctypes as C
     M, N, K, epi = shape
-    L = pkg.runtime.lib()
+    L = pkg.runtime.hooks()
     L.ptts_debug_gemm.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 2
     us, md = C.c_float(0), C.c_float(-1)
     rc = L.ptts_debug_gemm(M, N, K, 1, 50, epi, 1, C.byref(us), C.byref(md))
@@ -227,7 +227,7 @@ def test_many_row_gemm5_layer_scale_epilogue_rounds_like_the_reference(pkg):
     """residual + scale * (sums): k_gemm5 rounds the product and the sum one by one (the reference's r + s*v on amd64, mimi.go:275-285),
     k_gemm3 lets the compiler fuse them: the two may differ in the last bit, not more."""
     import ctypes as C
-    L = pkg.runtime.lib()
+    L = pkg.runtime.hooks()
     L.ptts_debug_gemm.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)] * 2
     us, md = C.c_float(0), C.c_float(-1)
     rc = L.ptts_debug_gemm(16384, 512, 512, 1, 50, 0xa05, 1, C.byref(us), C.byref(md))

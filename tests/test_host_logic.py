@@ -24,6 +24,25 @@ def test_library_exports_every_declared_symbol(pkg):
     assert b"gfx950" in ctypes.cast(lib.ptts_version, ctypes.CFUNCTYPE(ctypes.c_char_p))()
 
 
+def test_product_library_exports_no_test_hooks(pkg):
+    """The library a host of the reference links (include/ptts.h) carries no fault injection, micro-benchmark, launch census or staged
+    decoder hook: those are declared in include/ptts_debug.h and exported by libptts_hooks.so alone (the reference's seam has nothing of the kind:
+    internal/tts/runtime.go:42-45)."""
+    dbg = open(os.path.join(ROOT, "include", "ptts_debug.h")).read()
+    hooks = set(re.findall(r"\b(ptts_[a-z0-9_]+)\s*\(", dbg))
+    assert hooks == set(pkg.runtime.HOOK_SYMBOLS), hooks ^ set(pkg.runtime.HOOK_SYMBOLS)
+    prod = set(re.findall(r"\b(ptts_[a-z0-9_]+)\s*\(", open(os.path.join(ROOT, "include", "ptts.h")).read()))
+    assert not (hooks & prod) and not any(s.startswith("ptts_debug") for s in prod), hooks & prod
+    import subprocess
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True, check=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if " T " in l and l.split()[-1].startswith("ptts_")}
+    ex_prod, ex_hooks = exported(pkg.runtime.LIB_PATH), exported(pkg.runtime.HOOKS_PATH)
+    assert not (ex_prod & hooks), ex_prod & hooks
+    assert not any("debug" in s for s in ex_prod), [s for s in ex_prod if "debug" in s]
+    assert ex_hooks == hooks, ex_hooks ^ hooks
+
+
 def test_plan_matches_checkpoint_shapes(pkg, tmp_path):
     cfg = pkg.synth.SynthConfig.tiny()
     path = str(tmp_path / "tiny.safetensors")

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptts_amd
 
 pkg = ptts_amd.load()
-L = pkg.runtime.lib()
+L = pkg.runtime.hooks()   # the measurement entry points live in libptts_hooks.so (include/ptts_debug.h)
 L.ptts_debug_time_skinny.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)]
 shapes = [("in_proj", 3072, 1024), ("out_proj", 1024, 1024), ("linear1", 4096, 1024), ("linear2", 1024, 4096), ("flow 512x512", 512, 512),
           ("ada_all", 10240, 512), ("eos", 1, 1024), ("input_linear", 1024, 32)]

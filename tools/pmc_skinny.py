@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptts_amd
 
 pkg = ptts_amd.load()
-L = pkg.runtime.lib()
+L = pkg.runtime.hooks()   # the measurement entry points live in libptts_hooks.so (include/ptts_debug.h)
 L.ptts_debug_time_skinny.argtypes = [C.c_int32] * 7 + [C.POINTER(C.c_float)]
 for name, N, K, S, ln in [("eos", 1, 1024, 1, 0), ("flow512", 512, 512, 1, 1), ("qkv", 3072, 1024, 1, 1), ("ffn2", 1024, 4096, 4, 0)]:
     us = C.c_float(0)

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ptts_amd
 
 pkg = ptts_amd.load()
-L = pkg.runtime.lib()
+L = pkg.runtime.hooks()   # the measurement entry points live in libptts_hooks.so (include/ptts_debug.h)
 L.ptts_debug_skinny_stamps.argtypes = [C.c_int32] * 6 + [C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
 names = ["entry", "w issued", "x+LN done", "staged+sync", "mfma done", "k-reduce", "stored"]
 for name, N, K, S, ln in [("eos", 1, 1024, 1, 0), ("flow512", 512, 512, 1, 1), ("out_proj", 1024, 1024, 1, 0), ("qkv", 3072, 1024, 1, 1),

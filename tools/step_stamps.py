@@ -12,7 +12,7 @@ import bench
 import ptts_amd
 
 pkg = ptts_amd.load()
-L = pkg.runtime.lib()
+L = pkg.runtime.hooks()   # the measurement entry points live in libptts_hooks.so (include/ptts_debug.h)
 wl = bench.WORKLOADS["b64_10s_bf16"]
 cfg = pkg.synth.SynthConfig.full()
 path = bench.checkpoint_path(pkg, wl["file"], 0, lambda: None)
