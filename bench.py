@@ -279,6 +279,60 @@ def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_c
     return clients * per_client * wl["frames"] * FRAME_SEC, dt, statistics.median(lat), st["mean_batch"]
 
 
+def serve_mixed_pass(pkg, model, wl, voice, barrier, sync, slots=192, clients=384, per_client=2):
+    """The serving leg on what real traffic looks like once EOS is finite: utterances of 2-12 s (budgets drawn uniformly from 25..150 frames per request)
+    through ONE continuous-batching engine of `slots` utterances (csrc/continuous.cpp: slots refilled between groups of AR steps, finished utterances decoded
+    beside the following steps; internal/server/server.go:398-421 + internal/tts/service.go:138-153 are the reference's counterparts), closed-loop clients.
+    Returns (audio seconds, wall seconds, p50 latency, mean occupied slots) of the timed round."""
+    import random
+    import threading
+    eng = model.share()
+    try:
+        eng.set_max_batch(slots)
+        eng.set_use_graph(False)
+        prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
+        warm = gen_cfgs(pkg, wl, 1, voice, pcm16=True)[0]
+        eng.generate_batch(prompts[:slots], [warm] * slots)     # the engine's buffers (KV caches at this width, result pool) exist before anything is timed
+        plan = random.Random(5)
+        frames = [plan.randint(25, 150) for _ in range(4096)]
+        disp = pkg.Dispatcher([eng], max_batch=slots, window_us=3000, continuous=True, cont_kv_capacity=512, cont_max_steps=256)
+        lat, done = [], []
+        lock = threading.Lock()
+
+        def client(i, n):
+            for k in range(n):
+                nf = frames[(i * per_client + k) % len(frames)]
+                c = pkg.RuntimeGenerateConfig(temperature=0.0, eos_threshold=float("inf"), max_steps=nf, lsd_decode_steps=1, frames_after_eos=3, device_voice=voice, pcm16=True)
+                t0 = time.perf_counter()
+                r = disp.generate(prompts[(i * per_client + k) % len(prompts)], c)
+                dt = time.perf_counter() - t0
+                assert r.n_frames == nf
+                with lock:
+                    lat.append(dt)
+                    done.append(nf)
+
+        def round_(n):
+            ts = [threading.Thread(target=client, args=(i, n)) for i in range(clients)]
+            [t.start() for t in ts]
+            [t.join() for t in ts]
+
+        round_(1)
+        lat.clear(); done.clear()
+        st0 = disp.stats()
+        sync(); barrier()
+        t0 = time.perf_counter()
+        round_(per_client)
+        sync()
+        dt = time.perf_counter() - t0
+        barrier()
+        st = disp.stats()
+        disp.close()
+        occ = (st["cont_slot_steps"] - st0["cont_slot_steps"]) / max(1, st["cont_steps"] - st0["cont_steps"])
+        return sum(done) * FRAME_SEC, dt, statistics.median(lat), occ, st["flow_cluster_fallbacks"]
+    finally:
+        eng.close()
+
+
 def run_workload(pkg, model, wl, prompts, voice, steps, warmup, barrier, sync, **cfg_kw):
     cfgs = gen_cfgs(pkg, wl, len(prompts), voice, **cfg_kw)
     toks = [np.ascontiguousarray(p, np.int64) for p in prompts]
@@ -674,6 +728,17 @@ def main():
                                               f"requests of {wl['frames']} frames, PCM16; {world} GPU(s), no exchange between them"}
         except Exception as e:  # noqa: BLE001
             log(f"[bench] serve-mode pass failed: {e}")
+        try:
+            a_m, dt_m, p50_m, occ_m, fb_m = serve_mixed_pass(pkg, model, wl, voice, barrier, sync)
+            dt_all = max_over_ranks(dt_m, world, dev)
+            a_all = sum(gather_over_ranks(a_m, world, dev))
+            result.setdefault("serve_mode", {})["mixed_continuous"] = {
+                "value": round(a_all / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_m, 1),
+                "per_rank_xrt": [round(x / dt_all, 1) for x in gather_over_ranks(a_m, world, dev)], "mean_occupied_slots": round(occ_m, 1), "flow_cluster_fallbacks": fb_m,
+                "config": f"per GPU: one continuous-batching engine of 192 slots (ptts_dispatch_opts.continuous), 384 closed-loop clients x 2 requests of 25..150 frames "
+                          f"(2-12 s, uniformly drawn), PCM16; {world} GPU(s), no exchange between them"}
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] mixed-length serve pass failed: {e}")
     if rank == 0:
         try:
             result["roofline"] = roofline_pass(pkg, model, wl, prompts, voice, traffic)

@@ -32,7 +32,8 @@
 namespace ptts {
 
 namespace {
-// The pacing below was swept on one MI355X at 128 clients, utterances of 2-12 s (profiles/r4_serve_sweep.txt; tools/gpu_cont_trace.sh):
+// The pacing below was swept on one MI355X at 128 clients, utterances of 2-12 s (profiles/r4_serve_sweep.txt; tools/gpu_cont_trace.sh), and again in round 5 at
+// 128-256 slots (profiles/r5_serve_sweep.txt: decodes of 16 / 32 / 48 utterances alike; 85 / 96 CUs for the decoder -12..-30 %, 160 / 256 CUs -3..-5 %):
 constexpr int kDecoderShare = 2;      // the decoder's stream gets 1 / kDecoderShare of the device's CUs (128 of the MI355X's 256): see cont_create
 constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
 constexpr int kDecodeMaxAge = 8;      // ... or the oldest has waited this many groups of steps (a caller waiting for audio is a caller not sending its next request)

@@ -184,9 +184,11 @@ def test_cancellation_callbacks_and_oversized_requests(pkg, tiny):
         d.close()
 
 
-def test_full_size_64_slots_mixed_lengths_finite_eos_against_stand_alone_and_oracle(pkg):
-    """The configuration tools/serve_bench.py measures: the b6369a24 shapes, bf16 weights AND bf16 KV cache, 64 slots, KV capacity 512, one device
-    voice, 144 requests with budgets of 25..150 frames (2-12 s), a third of them ending by a FINITE EOS threshold, through the continuous engine.
+@pytest.mark.parametrize("slots,n", [(64, 144), (192, 330)])
+def test_full_size_mixed_lengths_finite_eos_against_stand_alone_and_oracle(pkg, slots, n):
+    """The configurations tools/serve_bench.py and bench.py's serve_mode measure: the b6369a24 shapes, bf16 weights AND bf16 KV cache, 64 slots (round 4) and
+    192 slots (round 5: the AR step takes up to 256 rows; the setting the mixed-length serving figure is quoted on), KV capacity 512, one device
+    voice, 144 / 330 requests with budgets of 25..150 frames (2-12 s), a third of them ending by a FINITE EOS threshold, through the continuous engine.
 
     A random-init model amplifies any rounding difference by ~1.15 per step (tests/test_gpu_fullsize.py), and a request's prompt is prefilled by
     different GEMM tilings inside the engine (a few newcomers at a time) and on its own -- so over 150 free-running frames the two trajectories part,
@@ -200,10 +202,9 @@ def test_full_size_64_slots_mixed_lengths_finite_eos_against_stand_alone_and_ora
     cfg = pkg.synth.SynthConfig.full()
     path = bench.checkpoint_path(pkg, "BF16", 0, lambda: None)
     voice = bench.voice_modules(pkg, cfg)
-    gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=64)
+    gm = pkg.Model.open(path, device=0, weights=pkg.WEIGHTS_BF16, kv=pkg.KV_BF16, max_batch=slots)
     dv = gm.upload_voice(pkg.VoiceModelState(voice))
     rng = np.random.default_rng(77)
-    n = 144
     prompts = [p for p in pkg.synth.make_prompts(n, 25, 4000, seed=13)]
     steps = [int(rng.integers(25, 151)) for _ in range(n)]
     base = [pkg.RuntimeGenerateConfig(max_steps=steps[i], eos_threshold=float("inf"), frames_after_eos=3, device_voice=dv, want_latents=True, pcm16=True) for i in range(n)]
@@ -247,12 +248,14 @@ def test_full_size_64_slots_mixed_lengths_finite_eos_against_stand_alone_and_ora
         w = gm.generate_batch([prompts[i]], [cfgs[i]])[0]
         assert (w.eos_step, w.n_frames) == (es, nf), (i, w.eos_step, w.n_frames, es, nf)
         want[i] = w
-    d = pkg.Dispatcher([gm], max_batch=64, window_us=3000, continuous=True, cont_kv_capacity=512, cont_max_steps=256)
+    d = pkg.Dispatcher([gm], max_batch=slots, window_us=3000, continuous=True, cont_kv_capacity=512, cont_max_steps=256)
     try:
         got, errs = run_clients(d, prompts, cfgs, stagger_s=0.0002)
         assert not any(errs), [e for e in errs if e][:3]
         st = d.stats()
-        assert st["requests"] == n and st["batches"] >= 3, st
+        assert st["requests"] == n and st["batches"] >= 3 and st["flow_cluster_fallbacks"] == 0, st
+        if slots > 64:
+            assert st["cont_slot_steps"] / max(1, st["cont_steps"]) > 64, st   # more than 64 utterances per step on average: the wide step really ran
     finally:
         d.close()
     worst_head, worst_lsb = 0.0, 0
@@ -273,8 +276,8 @@ def test_full_size_64_slots_mixed_lengths_finite_eos_against_stand_alone_and_ora
             ref16 = O.pcm16(pcm[k, : got[i].n_frames * 1920])
             worst_lsb = max(worst_lsb, int(np.abs(got[i].pcm.astype(np.int32) - ref16.astype(np.int32)).max()))
     from _parity import record
-    record("continuous full size: first 6 frames vs stand-alone (144 requests, bf16 weights + KV)", worst_head, 0.0, scale, (1e-3, 0))
-    record("continuous full size: pcm16 vs the decoder on the request's own latents (144 requests)", float(worst_lsb), 0.0, 32767.0, (2, 0))
+    record(f"continuous full size, {slots} slots: first 6 frames vs stand-alone ({n} requests, bf16 weights + KV)", worst_head, 0.0, scale, (1e-3, 0))
+    record(f"continuous full size, {slots} slots: pcm16 vs the decoder on the request's own latents ({n} requests)", float(worst_lsb), 0.0, 32767.0, (2, 0))
     assert worst_head <= 1e-3 * max(1.0, scale), (worst_head, scale)
     assert worst_lsb <= 2, worst_lsb
     om = O.OracleModel.from_file(path)

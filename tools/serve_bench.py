@@ -3,7 +3,8 @@ back through Dispatcher.generate; reports aggregate xRT, utterance latency and t
 
     python tools/serve_bench.py [clients ...]        e.g.  python tools/serve_bench.py 1 8 64 128
 Environment: PTTS_ENGINES (engines per GPU), PTTS_WINDOW_US, PTTS_PER_CLIENT, PTTS_CONTINUOUS=1 (continuous batching),
-PTTS_MIXED=1 (utterances of 2-12 s, uniformly drawn per request, instead of 10 s each: what EOS does to real traffic).
+PTTS_MIXED=1 (utterances of 2-12 s, uniformly drawn per request, instead of 10 s each: what EOS does to real traffic),
+PTTS_SLOTS (utterances per engine, default 64).
 """
 import os
 import statistics
@@ -23,7 +24,8 @@ path = bench.checkpoint_path(pkg, wl["file"], 0, lambda: None)
 # PTTS_ENGINES=2: two engines (KV caches, workspaces, streams) over ONE weight arena on the same GPU: batch k+1's prefill and AR
 # loop (latency-bound, most of the chip idle) run beside batch k's Mimi decode (throughput work)
 n_eng = int(os.environ.get("PTTS_ENGINES", "1"))
-kw = dict(device=0, weights=wl["weights"], kv=wl["kv"], max_batch=64)
+SLOTS = int(os.environ.get("PTTS_SLOTS", "64"))   # utterances per engine: the batch collector's max_batch / the continuous engine's slots (up to 256)
+kw = dict(device=0, weights=wl["weights"], kv=wl["kv"], max_batch=SLOTS)
 models = [pkg.Model.open(path, **kw)]
 models += [models[0].share() for _ in range(n_eng - 1)]
 model = models[0]
@@ -41,9 +43,9 @@ frame_plan = [lens.randint(25, 150) if mixed else FRAMES for _ in range(4096)]
 # and the page-locked result pool (~0.5 s)
 for m_, v_ in zip(models, voices):
     wc = pkg.RuntimeGenerateConfig(max_steps=FRAMES, eos_threshold=float("inf"), frames_after_eos=3, device_voice=v_, pcm16=True)
-    m_.generate_batch(prompts[:64], [wc] * 64)
+    m_.generate_batch(prompts[:SLOTS], [wc] * SLOTS)
 for clients in [int(a) for a in sys.argv[1:]] or [1, 8, 32, 64, 128]:
-    disp = pkg.Dispatcher(models, max_batch=64, window_us=window_us, continuous=continuous, cont_kv_capacity=512, cont_max_steps=256,
+    disp = pkg.Dispatcher(models, max_batch=SLOTS, window_us=window_us, continuous=continuous, cont_kv_capacity=512, cont_max_steps=256,
                           cont_steps_per_group=int(os.environ.get("PTTS_CONT_GROUP", "0")))
     lat, frames_done = [], []
     lock = threading.Lock()
