@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
 //   K image (per half hi / lo): [32 keys][128 B = 64 dims bf16], the 16-byte chunk c (dims 8c .. 8c+7) of key k at position c ^ ((k >> 1) & 7): the
 //     fragment read of step i (lane: key = lane & 31, g = lane >> 5 -> chunk 2i + g) is conflict-free for every 16 lanes.
 //   V^T image (per half): [64 dims][64 B = 32 keys bf16 in the ORDER the score registers hold them: position 16 i + 8 g + 4 b + e = key 16 i + 8 b + 4 g + e],
-//     chunk c = 2i + g of dim d at position c ^ ((d >> 2) & 3).
+//     chunk c = 2i + g of dim d at position c ^ aw_vswz(d) (conflict-free for the fragment reads AND for the staging stores: see aw_vswz).
 // Two buffers: the loads of tile t + 1 are requested before tile t is multiplied, split and written behind it, one barrier per tile.
 // Tiles are aligned to the block's first visible key (not each wave's own): the sums of a row are grouped differently from the kernel above for the first
 // context + 96 positions of an utterance -- rounding-order differences, held by the same tolerances.
@@ -206,6 +206,12 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
 constexpr int AW_KB = 32 * 128;   // bytes of one K half image
 constexpr int AW_VB = 64 * 64;    // bytes of one V^T half image
 constexpr int AW_TILE = 2 * AW_KB + 2 * AW_VB;   // 16 KB per tile: K hi | K lo | V^T hi | V^T lo
+
+// chunk swizzle of the V^T image (64 rows of 64 B: four 16-byte chunks per row).  Round 4's (row >> 2) & 3 kept the fragment READS conflict-free but put the rows r and
+// r + 2 that one 8-lane service group of the staging ds_write_b128 stores to on the same banks (a row is 64 B, the store banks repeat every 128 B): 2-way on
+// every V^T store = the 5.87e6 conflict cycles on 6.12e6 LDS instructions of profiles/r4_pmc_mimi.txt (bank model: tools/probes/lds_conflicts.py's functions,
+// 16 cycles per store instead of 8).  This one is conflict-free for both (model: 8 / 4): bit 0 = row bit 2, bit 1 = row bit 1 ^ row bit 3.
+__device__ __forceinline__ int aw_vswz(int row) { return ((row >> 2) & 1) | ((((row >> 1) ^ (row >> 3)) & 1) << 1); }
 
 template <int NW>   // waves = 32-query tiles per block (4: 128 queries, 12 key tiles of which a wave uses 9; 2: 64 queries, 10 of which it uses 9)
 __global__ __launch_bounds__(64 * NW) void k_attn_window_lds(AttnArgs a, int qblocks) {
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_window_lds(AttnArgs a, int qbl
             const int id = tid + 64 * NW * u;
             const int sk = id >> 3, sc = id & 7, sd = id & 63, sg = id >> 6;
             const int k_dst = sk * 128 + ((sc ^ ((sk >> 1) & 7)) << 4);
-            const int v_dst = sd * 64 + ((sg ^ ((sd >> 2) & 3)) << 4);
+            const int v_dst = sd * 64 + ((sg ^ aw_vswz(sd)) << 4);
             uint4 hq, lq;
             split2w(sk0[u].x, sk0[u].y, hq.x, lq.x);
             split2w(sk0[u].z, sk0[u].w, hq.y, lq.y);
@@ -300,7 +306,7 @@ __global__ __launch_bounds__(64 * NW) void k_attn_window_lds(AttnArgs a, int qbl
     float m = -INFINITY, l = 0.0f;
     // fragment addresses of this lane inside a tile buffer
     const int ka = j * 128, ksw = (j >> 1) & 7;            // K: chunk 2 i + half
-    const int va0 = j * 64, va1 = (j + 32) * 64, vsw0 = (j >> 2) & 3, vsw1 = ((j + 32) >> 2) & 3;   // V^T rows j and 32 + j: chunk 2 i + half
+    const int va0 = j * 64, va1 = (j + 32) * 64, vsw0 = aw_vswz(j), vsw1 = aw_vswz(j + 32);   // V^T rows j and 32 + j: chunk 2 i + half
 
     stage_load(jb_lo);
     stage_store(lds);

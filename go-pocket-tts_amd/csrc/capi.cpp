@@ -106,6 +106,15 @@ int ptts_model_share(ptts_model* base, ptts_model** out) {
     });
 }
 
+int ptts_model_replicate(ptts_model* base, int32_t device, ptts_model** out) {
+    return guard([&] {
+        if (!base || !base->m || !out) throw Error(PTTS_EINVAL, "ptts-hip: null argument");
+        std::unique_ptr<ptts_model> h(new ptts_model());
+        h->m = model_replicate(*base->m, device);
+        *out = h.release();
+    });
+}
+
 int ptts_model_set_use_graph(ptts_model* m, int32_t use_graph) {
     return guard([&] {
         if (!m || !m->m) throw Error(PTTS_EINVAL, "ptts-hip: null argument");

@@ -144,6 +144,48 @@ Model* model_share(Model& base) {
     return m.release();
 }
 
+// The model again on ANOTHER GPU of the same process: its own arena, filled from base's over the GPUs' direct link (hipMemcpyPeer: xGMI on an MI355X node) --
+// no second file read, no host staging, no collective library.  This is the shape the reference's server has: ONE process holding N workers
+// (internal/server/server.go:119-143,398-421; cmd/pockettts/serve.go:15-52); there the workers share one CPU model, here every GPU gets the bytes once at
+// start-up and a dispatcher over the N models deals the requests (dispatcher.cpp: one worker thread per model, each on its own device).  `device` may be
+// base's own (a second private copy on the same GPU: what a one-GPU box can test).
+Model* model_replicate(Model& base, int device) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) throw Error(PTTS_ENODEVICE, "ptts-hip: no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) throw Error(PTTS_ENODEVICE, strfmt("ptts-hip: device %d out of range (%d visible)", device, ndev));
+    std::unique_ptr<Model> m(new Model());
+    m->d = base.d;
+    m->opts = base.opts;
+    m->opts.device = device;
+    m->device = device;
+    m->noise_state = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count() ^ (uint64_t)(uintptr_t)m.get();
+    {   // base's arena is complete and idle-readable: nothing of base may be mid-upload (model_open returns after its copy)
+        std::lock_guard<std::mutex> lock(base.mu);
+        base.use_device();
+        PTTS_HIP(hipStreamSynchronize(base.stream));
+    }
+    m->use_device();
+    int lo = 0, hi = 0;
+    PTTS_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    PTTS_HIP(hipStreamCreateWithPriority(&m->stream, hipStreamNonBlocking, hi));
+    PTTS_HIP(hipStreamCreateWithPriority(&m->stream2, hipStreamNonBlocking, lo));
+    void* p = nullptr;
+    PTTS_HIP(hipMalloc(&p, m->d.total_bytes));
+    m->arena = reinterpret_cast<uint8_t*>(p);
+    m->own_arena = true;
+    if (device != base.device) {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, device, base.device) == hipSuccess && can) {
+            const hipError_t e = hipDeviceEnablePeerAccess(base.device, 0);   // (speed only: hipMemcpyPeer stages through the host without it)
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+            else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        }
+    }
+    PTTS_HIP(hipMemcpyPeer(m->arena, device, base.arena, base.device, m->d.total_bytes));
+    PTTS_HIP(hipDeviceSynchronize());
+    return m.release();
+}
+
 // timestep embedder (flow_net.go:42-83) for one (s, t) pair, then 0.5*(e_s + e_t) (flow_net.go:320-335)
 void Model::compute_tcomb(float sv, float tv, float* dst) {
     const int C = d.flow_dim, nf = d.nfreq;

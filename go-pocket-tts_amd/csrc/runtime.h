@@ -218,6 +218,7 @@ int resolve_max_steps(const ptts_request& r);                                   
 void enqueue_step(Batch& b, int lsd, bool use_graph, int nsteps = 1);           // nsteps > 1 only with use_graph
 void mimi_zero_history(Model& m, MimiWs& w, hipStream_t s);
 Model* model_share(Model& base);   // another engine over base's weight arena (base must outlive it)
+Model* model_replicate(Model& base, int device);   // the model on another GPU of this process: own arena, copied from base's by hipMemcpyPeer
 void generate(Model& m, const ptts_request* reqs, int n, ptts_result* res);
 std::string request_error(const Desc& d, const ptts_request& q);   // empty: the request is well formed
 

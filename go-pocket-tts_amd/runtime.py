@@ -97,7 +97,7 @@ ABI_SYMBOLS = [
     "ptts_op_attention_positions", "ptts_op_conv1d_leftpad", "ptts_op_convtr1d_righttrim", "ptts_version",
         "ptts_voice_create", "ptts_voice_free", "ptts_profile_enable", "ptts_profile_read", "ptts_plan_fill_host", "ptts_wav_header_streaming", "ptts_op_pcm16",
     "ptts_dispatcher_create", "ptts_dispatcher_create_custom", "ptts_dispatch_generate", "ptts_dispatcher_stats", "ptts_dispatcher_close",
-    "ptts_model_share", "ptts_model_set_use_graph", "ptts_model_set_max_batch", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
+    "ptts_model_share", "ptts_model_replicate", "ptts_model_set_use_graph", "ptts_model_set_max_batch", "ptts_text_estimate_max_frames", "ptts_text_frames_after_eos", "ptts_text_prepare", "ptts_text_chunks", "ptts_chunks_count",
     "ptts_chunks_get", "ptts_chunks_free",
     "ptts_tokenizer_open", "ptts_tokenizer_open_bytes", "ptts_tokenizer_free", "ptts_tokenizer_vocab_size", "ptts_tokenizer_encode",
     "ptts_tokenizer_encode_cb", "ptts_text_nfkc", "ptts_rccl_unique_id", "ptts_rccl_broadcast", "ptts_dsp_apply",
@@ -380,6 +380,13 @@ class Model:
         h = C.c_void_p()
         lib().ptts_model_share.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         _check(lib().ptts_model_share(self.h, C.byref(h)))
+        return Model(h.value)
+
+    def replicate(self, device: int) -> "Model":
+        """This model on another GPU of the process (own arena, filled from this one's by hipMemcpyPeer); independent of this one afterwards."""
+        h = C.c_void_p()
+        lib().ptts_model_replicate.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+        _check(lib().ptts_model_replicate(self.h, int(device), C.byref(h)))
         return Model(h.value)
 
     def close(self):

@@ -168,6 +168,11 @@ typedef struct ptts_result {
  * read-only): two engines on one GPU, e.g. behind one dispatcher, let one batch's Mimi decode run beside the next batch's
  * prefill + AR loop.  `base` must outlive the engine; a device voice belongs to the engine it was uploaded to. */
 int  ptts_model_share(ptts_model* base, ptts_model** out);
+/* The model on ANOTHER GPU of the same process (one process, N GPUs: the shape of the reference's single server with its N workers,
+ * internal/server/server.go:119-143,398-421): a private weight arena on `device`, copied from base's over the GPUs' direct link (hipMemcpyPeer) -- the file
+ * is read and decoded once, no collective library is involved.  Independent of `base` afterwards (either may be closed first).  A dispatcher over the N
+ * models (ptts_dispatcher_create) deals requests to them; a device voice belongs to the GPU it was uploaded to.  `device` may be base's own. */
+int  ptts_model_replicate(ptts_model* base, int32_t device, ptts_model** out);
 /* ptts_opts.use_graph of an open model, changed between calls (A/B measurement, hosts that become short of CPU) */
 int  ptts_model_set_use_graph(ptts_model* m, int32_t use_graph);
 /* ptts_opts.max_batch of an open model or engine (1..256), changed between calls: how many utterances of one ptts_generate call are stepped

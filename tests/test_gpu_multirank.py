@@ -43,3 +43,67 @@ def test_two_ranks_share_one_broadcast_arena(native):
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == line["rccl_ranks"] == 2 and len(line["per_rank_xrt"]) == 2 and line["scaling"] == "weak"
     assert line["value"] > 1.5 * min(line["per_rank_xrt"])   # two ranks' audio over the slower rank's time
+
+
+def _one_process_n_models(pkg, devices):
+    """One process, one model per entry of `devices` (the first opens the file, the others are ptts_model_replicate copies over the GPUs' direct link), ONE
+    dispatcher over all of them, 4 x len(devices) x 8 clients: every caller's audio equals the stand-alone audio of the first model (rows of a batch never
+    mix, every GPU holds the same weights), every model served batches, and the replicas survive the closing of the model they were copied from."""
+    import threading
+    import numpy as np
+    cfg = pkg.synth.SynthConfig.tiny()
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "tiny.safetensors")
+        pkg.synth.write_safetensors(path, pkg.synth.make_checkpoint(cfg, seed=99))
+        base = pkg.Model.open(path, device=devices[0], max_batch=8)
+        models = [base] + [base.replicate(d) for d in devices[1:]]
+        assert [m.info.arena_bytes for m in models] == [base.info.arena_bytes] * len(models)
+        prompts = [p.tolist() for p in pkg.synth.make_prompts(16, 7, cfg.n_bins, seed=3)]
+        c = pkg.RuntimeGenerateConfig(max_steps=5, eos_threshold=float("inf"), frames_after_eos=3, want_latents=True)
+        want = base.generate_batch(prompts[:8], [c] * 8) + base.generate_batch(prompts[8:], [c] * 8)
+        for m in models[1:]:                               # a replica alone gives the bits of the original: the same kernels on the same bytes
+            got = m.generate_batch(prompts[:8], [c] * 8)
+            for a, b in zip(got, want[:8]):
+                assert np.array_equal(a.latents, b.latents) and np.array_equal(a.pcm, b.pcm)
+        d = pkg.Dispatcher(models, max_batch=8, window_us=2000)
+        n_clients = 4 * len(models) * 8
+        res, errs = [None] * n_clients, [None] * n_clients
+
+        def client(i):
+            try:
+                res[i] = d.generate(prompts[i % 16], c)
+            except Exception as e:  # noqa: BLE001
+                errs[i] = e
+
+        ts = [threading.Thread(target=client, args=(i,)) for i in range(n_clients)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        st = d.stats()
+        d.close()
+        assert not any(errs), [str(e) for e in errs if e][:3]
+        for i in range(n_clients):
+            assert res[i].n_frames == want[i % 16].n_frames
+            np.testing.assert_allclose(res[i].latents, want[i % 16].latents, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want[i % 16].latents).max())))
+        assert st["requests"] == n_clients and st["batches"] >= len(models), st
+        base.close()                                       # the replicas own their arenas
+        for m in models[1:]:
+            got = m.generate_batch(prompts[:8], [c] * 8)
+            for a, b in zip(got, want[:8]):
+                assert np.array_equal(a.latents, b.latents)
+            m.close()
+
+
+def test_one_process_dispatcher_over_replicas_on_one_gpu(pkg):
+    """The one-process / N-model start-up (ptts_model_replicate + one dispatcher: the shape of the reference's single server process,
+    internal/server/server.go:119-143,398-421, cmd/pockettts/serve.go:15-52) with both models on device 0: everything but the cross-GPU link of
+    hipMemcpyPeer, on a one-GPU box."""
+    _one_process_n_models(pkg, [0, 0])
+
+
+def test_one_process_dispatcher_over_models_on_every_gpu(pkg):
+    """The same over every GPU of the box (device 0's arena handed to devices 1..N-1 by hipMemcpyPeer, no RCCL): needs two GPUs."""
+    n = _gpus()
+    if n < 2:
+        pytest.skip("needs two GPUs")
+    _one_process_n_models(pkg, list(range(min(n, 8))))
