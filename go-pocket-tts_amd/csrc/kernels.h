@@ -112,6 +112,31 @@ struct SkinnyStampLog {
 extern thread_local SkinnyStampLog* g_skinny_stamp_log;
 extern thread_local hipEvent_t g_skinny_ev[2];   // when set, launch_skinny times the dispatch with them (hipExtLaunchKernel)
 
+// The AR step's big linears at 128+ rows (tall.hip): row preparation once per row, then a 64 x 64-tile product whose operands both stream through LDS.
+struct PrepArgs {   // x' = x + (sum of psplit planes, in order) + pbias -> x_out; LayerNorm(x') -> bf16 hi / lo planes [M][ldy] (and f32 rows to y_out)
+    const float* x = nullptr; int64_t ldx = 0;
+    const float* partial = nullptr; int psplit = 0; int64_t pstride = 0; const float* pbias = nullptr;   // planes [psplit][M][D]
+    float* x_out = nullptr;                                                                            // dense [M][D]; written only with `partial`
+    const float* ln_w = nullptr; const float* ln_b = nullptr; float eps = 1e-5f;
+    uint16_t* yh = nullptr; uint16_t* yl = nullptr; int64_t ldy = 0;
+    float* y_out = nullptr;
+    int M = 0, D = 0;
+};
+bool rowprep_supported(const PrepArgs& a);
+void launch_rowprep(const PrepArgs& a, hipStream_t stream);
+struct TallArgs {   // C[M,N] = epi(A[M,K] * W[N,K]^T + bias), A = ah + al (bf16 planes), W the fragment-ordered bf16 copy (Linear::wt)
+    const uint16_t* ah = nullptr; const uint16_t* al = nullptr; int64_t lda = 0;
+    const void* Wt = nullptr; const float* bias = nullptr;
+    const float* R = nullptr; int64_t ldr = 0;                     // EPI_RESADD; with splitk > 1: added (with the bias) into plane 0
+    float* C = nullptr; int64_t ldc = 0;                           // f32 result, or
+    uint16_t* ch = nullptr; uint16_t* cl = nullptr; int64_t ldp = 0;   // the result as bf16 hi / lo planes (the next product's A)
+    float* partial = nullptr; int64_t zstride = 0; int splitk = 1; // splitk > 1: planes [splitk][M][N]
+    int M = 0, N = 0, K = 0, epi = EPI_NONE;
+};
+constexpr int kTallMinRows = 128;   // from this many rows the step's in_proj / linear1 / linear2 run on k_tall (below, k_skinny's one-block-per-CU shape wins)
+bool tall_supported(const TallArgs& a);
+void launch_tall(const TallArgs& a, hipStream_t stream);
+
 struct LnArgs {
     const float* x = nullptr; RowMap xmap;
     const float* w = nullptr; const float* b = nullptr;  // null -> no affine (flow_net.go:228)

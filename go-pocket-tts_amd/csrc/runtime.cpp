@@ -319,6 +319,18 @@ Batch* batch_new(Model& m, int n_slots, int cap, int max_steps) {
             if (getenv("PTTS_FC_STAMPS")) { b->fc_stamps.ensure((size_t)8 * kFlowClusterMaxTiles * 64 * 8); PTTS_HIP(hipMemsetAsync(b->fc_stamps.p, 0, (size_t)8 * kFlowClusterMaxTiles * 64 * 8, m.stream)); }
         }
     }
+    {   // tall.hip: from kTallMinRows rows the layer's in_proj / linear1 / linear2 run as 64 x 64-tile products on bf16 row planes
+        const char* sw = getenv("PTTS_TALL");   // A/B switch, read per batch: 0 = k_skinny for every row count
+        bool ok = !(sw && sw[0] == '0') && n_slots >= kTallMinRows && (d.d_model == 512 || d.d_model == 1024) && d.ffn % 128 == 0;
+        for (int l = 0; ok && l < d.n_layers; l++) {
+            const auto& L = d.layers[l];
+            for (const Lin* li : {&L.in_proj, &L.l1, &L.l2}) ok = ok && li->bf16 && !li->wt_i8 && li->wt != NONE && li->out % 4 == 0;
+            ok = ok && L.in_proj.in == d.d_model && L.l1.in == d.d_model && L.l1.out == d.ffn && L.l2.in == d.ffn && L.l2.out == d.d_model;
+            ok = ok && L.n1.w != NONE && L.n1.b != NONE && L.n2.w != NONE && L.n2.b != NONE;
+        }
+        b->tall_ok = ok;
+        if (ok) { b->tp_a.ensure(2 * B * d.d_model * sizeof(uint16_t)); b->tp_f.ensure(2 * B * d.ffn * sizeof(uint16_t)); }
+    }
     PTTS_HIP(hipHostMalloc((void**)&b->n_active_pinned, sizeof(int32_t) * (size_t)(2 + 2 * B), hipHostMallocDefault));
     PTTS_HIP(hipHostMalloc((void**)&b->rows_pinned, sizeof(PcmRow) * std::max<size_t>((size_t)B, 1), hipHostMallocDefault));
     batch_reset(*b);
@@ -734,9 +746,32 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
     // with S = 2 (a full batch on bf16 weights) two row images per block instead of three (residual, two planes) plus the bias.
     Pending pend;
     const float* xin = x;   // where the current residual rows are read from: x, or plane 0 while a split sum is pending
+    // 128 rows and more (tall.hip): the prologue once per row (k_rowprep -> bf16 row planes), in_proj / linear1 / linear2 as 64 x 64-tile products (k_tall)
+    const bool tall = b.tall_ok && B >= kTallMinRows;
+    uint16_t* pa_h = tall ? b.tp_a.as<uint16_t>() : nullptr; uint16_t* pa_l = tall ? pa_h + (size_t)B * D : nullptr;
+    uint16_t* pf_h = tall ? b.tp_f.as<uint16_t>() : nullptr; uint16_t* pf_l = tall ? pf_h + (size_t)B * d.ffn : nullptr;
+    auto prep = [&](const float* rows, const Pending& pd, const Norm& nm) {
+        PrepArgs pa;
+        pa.x = rows; pa.ldx = D; pa.partial = pd.partial; pa.psplit = pd.splitk; pa.pstride = pd.pstride; pa.pbias = pd.bias;
+        pa.x_out = pd.partial ? x : nullptr;
+        pa.ln_w = m.at<float>(nm.w); pa.ln_b = m.at<float>(nm.b); pa.eps = nm.eps;
+        pa.yh = pa_h; pa.yl = pa_l; pa.ldy = D; pa.M = B; pa.D = D;
+        if (!rowprep_supported(pa)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the row preparation kernel");
+        launch_rowprep(pa, s);
+    };
+    auto tall_lin = [&](const uint16_t* ah, const uint16_t* al, const Lin& li, TallArgs t) {
+        t.ah = ah; t.al = al; t.lda = li.in; t.Wt = m.arena + li.wt; t.bias = m.at<float>(li.b); t.M = B; t.N = li.out; t.K = li.in;
+        if (!tall_supported(t)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the 64-row step linear");
+        launch_tall(t, s);
+    };
     for (int l = 0; l < d.n_layers; l++) {
         const auto& L = d.layers[l];
-        {
+        if (tall) {
+            prep(xin, pend, L.n1);
+            pend = Pending{}; xin = x;
+            TallArgs t; t.C = qkv; t.ldc = 3 * D;
+            tall_lin(pa_h, pa_l, L.in_proj, t);
+        } else {
             FusedIn in;
             in.pend = pend; in.x_out = pend.partial ? x : nullptr; in.norm = &L.n1; in.eps = L.n1.eps;
             step_fused_linear(b, xin, in, L.in_proj, qkv, 3 * D, B, EPI_NONE, nullptr, nullptr, 1.0f);
@@ -758,6 +793,19 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
             GemmArgs go = mk(m, attn, flat(D), L.out_proj, x, flat(D), B);
             go.R = x; go.epi = EPI_RESADD;
             step_gemm(m, go);
+        }
+        if (tall) {
+            prep(x, Pending{}, L.n2);
+            TallArgs t1; t1.ch = pf_h; t1.cl = pf_l; t1.ldp = d.ffn; t1.epi = EPI_GELU;   // gelu(linear1) leaves as the planes linear2 reads
+            tall_lin(pa_h, pa_l, L.l1, t1);
+            const int S = std::max(1, std::min(4, d.ffn / 1024));   // 1024-deep K slices: 16 x rows / 64 x S blocks of 8 chunks
+            float* planes = b.partial.as<float>();
+            TallArgs t2; t2.R = x; t2.ldr = D;
+            if (S > 1) { t2.splitk = S; t2.partial = planes; t2.zstride = (int64_t)B * D; }
+            else { t2.epi = EPI_RESADD; t2.C = x; t2.ldc = D; }
+            tall_lin(pf_h, pf_l, L.l2, t2);
+            if (S > 1) { xin = planes; pend.partial = planes + (size_t)B * D; pend.splitk = S - 1; pend.pstride = (int64_t)B * D; pend.bias = nullptr; }
+            continue;
         }
         {
             FusedIn in;

@@ -123,6 +123,9 @@ struct Batch {
     // the flow net's residual blocks as one launch (flow_cluster.hip): granule buffers and the tag / fault words; fc_ok: the model's shapes take it
     DevBuf fc_xbuf, fc_sync, fc_stamps;   // (fc_stamps: PTTS_FC_STAMPS measurement runs only)
     bool fc_ok = false;
+    // tall.hip (batches of kTallMinRows rows and more): bf16 hi + lo row planes of the normalised residual rows [2][B][d_model] and of gelu(linear1) [2][B][ffn]
+    DevBuf tp_a, tp_f;
+    bool tall_ok = false;
     bool tail_fused = false;   // the step's last transformer launch also produced sy (silu(t + cond_embed)): the flow part can be re-issued from `last` / `sy` / `cur` as they stand
     unsigned* fc_fault() const { return fc_sync.as<unsigned>() + 32 * kFlowClusterMaxTiles; }
     int par = 0;
