@@ -247,6 +247,68 @@ int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t var
     });
 }
 
+int ptts_debug_tall_linear(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t splitk, const float* x, const float* planes, int32_t psplit, const float* pbias,
+                           const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias, const float* R, int32_t out_planes, float* out,
+                           float* x_out) {
+    return guard([&] {
+        require_device();
+        if (!x || !W || !out || M <= 0 || N <= 0 || K <= 0 || K % 128) throw Error(PTTS_EINVAL, "ptts_debug_tall_linear: bad arguments");
+        const size_t mk = (size_t)M * K, mn = (size_t)M * N;
+        const int S = std::max(1, (int)splitk);
+        auto bf16 = [](float v) { uint32_t u; memcpy(&u, &v, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); };
+        auto f32 = [](uint16_t h) { uint32_t u = (uint32_t)h << 16; float v; memcpy(&v, &u, 4); return v; };
+        // the weights in the step kernels' fragment order (model.cpp add_tiled): [16-column tile][128-deep super-step][4][64 lanes] x 8 bf16
+        const size_t nt = ((size_t)N + 15) / 16, nss = (size_t)K / 128;
+        std::vector<uint16_t> wt(nt * nss * 4 * 64 * 8);
+        for (size_t t = 0; t < nt; t++)
+            for (size_t ss = 0; ss < nss; ss++)
+                for (int sidx = 0; sidx < 4; sidx++)
+                    for (int lane = 0; lane < 64; lane++)
+                        for (int j = 0; j < 8; j++) {
+                            const size_t n = t * 16 + (size_t)(lane & 15), k = ss * 128 + (size_t)(lane >> 4) * 32 + (size_t)sidx * 8 + j;
+                            wt[((((t * nss + ss) * 4 + sidx) * 64 + lane) * 8 + j)] = n < (size_t)N ? bf16(W[n * K + k]) : 0;
+                        }
+        Tmp dW(wt.size() * 2), dAh(mk * 2), dAl(mk * 2), dOut((size_t)S * mn * 4), dCh(mn * 2), dCl(mn * 2);
+        up(dW.p, wt.data(), wt.size() * 2);
+        Tmp dB((size_t)N * 4), dR(mn * 4), dX(mk * 4), dXo(mk * 4), dP(std::max<size_t>(1, (size_t)std::max(0, (int)psplit)) * mk * 4), dPb((size_t)K * 4), dLw((size_t)K * 4), dLb((size_t)K * 4);
+        if (bias) up(dB.p, bias, (size_t)N * 4);
+        if (R) up(dR.p, R, mn * 4);
+        if (ln_w) {   // the rows through k_rowprep: split-K planes + residual -> LayerNorm -> bf16 planes
+            up(dX.p, x, mk * 4); up(dLw.p, ln_w, (size_t)K * 4); up(dLb.p, ln_b, (size_t)K * 4);
+            PrepArgs pa;
+            pa.x = dX.as<float>(); pa.ldx = K; pa.ln_w = dLw.as<float>(); pa.ln_b = dLb.as<float>(); pa.eps = eps;
+            if (planes && psplit > 0) {
+                up(dP.p, planes, (size_t)psplit * mk * 4);
+                pa.partial = dP.as<float>(); pa.psplit = psplit; pa.pstride = (int64_t)mk; pa.x_out = dXo.as<float>();
+                if (pbias) { up(dPb.p, pbias, (size_t)K * 4); pa.pbias = dPb.as<float>(); }
+            }
+            pa.yh = dAh.as<uint16_t>(); pa.yl = dAl.as<uint16_t>(); pa.ldy = K; pa.M = M; pa.D = K;
+            if (!rowprep_supported(pa)) throw Error(PTTS_EINVAL, "ptts_debug_tall_linear: rows not taken by k_rowprep");
+            launch_rowprep(pa, nullptr);
+        } else {      // the rows as they are: split on the host the way the kernels split (hi = bf16(x), lo = bf16(x - hi))
+            std::vector<uint16_t> hi(mk), lo(mk);
+            for (size_t i = 0; i < mk; i++) { hi[i] = bf16(x[i]); lo[i] = bf16(x[i] - f32(hi[i])); }
+            up(dAh.p, hi.data(), mk * 2); up(dAl.p, lo.data(), mk * 2);
+        }
+        TallArgs t;
+        t.ah = dAh.as<uint16_t>(); t.al = dAl.as<uint16_t>(); t.lda = K; t.Wt = dW.p; t.bias = bias ? dB.as<float>() : nullptr;
+        t.R = R ? dR.as<float>() : nullptr; t.ldr = N; t.M = M; t.N = N; t.K = K; t.epi = epi;
+        if (S > 1) { t.splitk = S; t.partial = dOut.as<float>(); t.zstride = (int64_t)mn; }
+        else if (out_planes) { t.ch = dCh.as<uint16_t>(); t.cl = dCl.as<uint16_t>(); t.ldp = N; }
+        else { t.C = dOut.as<float>(); t.ldc = N; }
+        if (!tall_supported(t)) throw Error(PTTS_EINVAL, "ptts_debug_tall_linear: shape not taken by k_tall");
+        PTTS_HIP(hipMemset(dOut.p, 0xff, (size_t)S * mn * 4));   // (NaN where the kernel stores nothing)
+        launch_tall(t, nullptr);
+        PTTS_HIP(hipDeviceSynchronize());
+        if (S == 1 && out_planes) {
+            std::vector<uint16_t> hi(mn), lo(mn);
+            down(hi.data(), dCh.p, mn * 2); down(lo.data(), dCl.p, mn * 2);
+            for (size_t i = 0; i < mn; i++) out[i] = f32(hi[i]) + f32(lo[i]);
+        } else down(out, dOut.p, (size_t)S * mn * 4);
+        if (x_out && ln_w && planes && psplit > 0) down(x_out, dXo.p, mk * 4);
+    });
+}
+
 int ptts_mimi_layer_piece(ptts_model* h, int32_t layer, int32_t which, const float* x, int64_t rows, int32_t pos0, int32_t rows_per_seg, float* out) {
     return guard([&] {
         if (!h || !h->m) throw Error(PTTS_EINVAL, "native-safetensors runtime unavailable");

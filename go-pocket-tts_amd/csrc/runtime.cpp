@@ -734,7 +734,7 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
     Model& m = *b.m;
     const Desc& d = m.d;
     hipStream_t s = m.stream;
-    const int B = b.B, D = d.d_model, C = d.flow_dim, NA = d.ada_all.out;
+    const int B = b.B, D = d.d_model, C = d.flow_dim;
     const bool kvb = m.opts.kv == PTTS_KV_BF16;
     float* x = b.x.as<float>();
     float* qkv = b.qkv.as<float>();

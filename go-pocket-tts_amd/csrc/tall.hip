@@ -33,11 +33,19 @@ typedef __bf16 tl_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float tl_f32x2 __attribute__((ext_vector_type(2)));
 typedef float tl_f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TL_ROWS = 64, TL_COLS = 64, TL_KC = 128;       // block tile and K chunk
-constexpr int TL_PLANE = TL_ROWS * TL_KC * 2;                // bytes of one row plane of a stage (16 KB)
+constexpr int TL_COLS = 64, TL_KC = 128;                     // a block's columns and the K chunk; its rows are the template parameter ROWS (64, or 32 up to 128 rows:
+                                                             // twice the blocks, each taking in two thirds of the bytes -- a 128-row launch has 96..128 blocks of 64 rows)
 constexpr int TL_W = TL_COLS * TL_KC * 2;                    // bytes of the weight pieces of a stage (16 KB)
-constexpr int TL_STAGE = 2 * TL_PLANE + TL_W;                // 48 KB
-constexpr int TL_NS = 3;
+constexpr int TL_LDS = 160 * 1024;
+template <int ROWS> struct TlShape {
+    static constexpr int PLANE = ROWS * TL_KC * 2;           // bytes of one row plane of a stage (16 KB at 64 rows)
+    static constexpr int STAGE = 2 * PLANE + TL_W;           // 48 KB / 32 KB
+    static constexpr int NS = TL_LDS / STAGE;                // ring depth: 3 / 5 stages
+    static constexpr int WAVES = ROWS / 16 * 4;              // 16 / 8
+    static constexpr int APIECES = 2 * ROWS / 4 / WAVES;     // 1-KB pieces of the two row planes per wave and chunk (2)
+    static constexpr int WPIECES = 16 / WAVES;               // ... of the weights (1 / 2)
+    static constexpr int PIECES = APIECES + WPIECES;
+};
 
 union TlFrag {
     tl_bf16x8 v;
@@ -64,8 +72,10 @@ __device__ __forceinline__ void tl_dma1k(const char* src_lane, char* dst) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(src_lane) : "memory");
 }
 
-template <bool PLANES>
-__global__ __launch_bounds__(1024) void k_tall(TallArgs a) {
+template <bool PLANES, int ROWS>
+__global__ __launch_bounds__(ROWS * 16) void k_tall(TallArgs a) {
+    using S = TlShape<ROWS>;
+    constexpr int TL_PLANE = S::PLANE, TL_STAGE = S::STAGE, TL_NS = S::NS, TL_ROWS = ROWS;
     __shared__ __attribute__((aligned(16))) char lds[TL_NS * TL_STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int cg = wave & 3, rt = wave >> 2;                 // this wave's column tile and row tile inside the block
@@ -82,15 +92,22 @@ __global__ __launch_bounds__(1024) void k_tall(TallArgs a) {
     const int pchunk = (lane & 15) ^ tl_swz(prow & 15);
     const char* a_hi = reinterpret_cast<const char*>(a.ah) + (grow * a.lda + pchunk * 8) * 2;
     const char* a_lo = reinterpret_cast<const char*>(a.al) + (grow * a.lda + pchunk * 8) * 2;
-    // weights, piece `wave`: column tile wave >> 2 of the block, MFMA step wave & 3 of the chunk's super-step (model.cpp add_tiled: [tile][ss][4][64 lanes] x 16 B)
-    const int wtile = min(blockIdx.x * 4 + (wave >> 2), (a.N + 15) / 16 - 1);
-    const char* w_src = reinterpret_cast<const char*>(a.Wt) + ((((int64_t)wtile * nss_all) * 4 + (wave & 3)) * 64 + lane) * 16;
+    // weights: 16 pieces per chunk (column tile p >> 2 of the block, MFMA step p & 3 of the chunk's super-step; model.cpp add_tiled: [tile][ss][4][64 lanes] x 16 B);
+    // wave w copies piece w (and w + 8 when the block has 8 waves)
+    const char* w_src[S::WPIECES];
+#pragma unroll
+    for (int i = 0; i < S::WPIECES; i++) {
+        const int p = wave + i * S::WAVES;
+        const int wtile = min(blockIdx.x * 4 + (p >> 2), (a.N + 15) / 16 - 1);
+        w_src[i] = reinterpret_cast<const char*>(a.Wt) + ((((int64_t)wtile * nss_all) * 4 + (p & 3)) * 64 + lane) * 16;
+    }
     auto issue = [&](int ch) {
         char* st = lds + (ch % TL_NS) * TL_STAGE;
         const int ss = ss0 + ch;
         tl_dma1k(a_hi + (int64_t)ss * (TL_KC * 2), st + wave * 1024);
         tl_dma1k(a_lo + (int64_t)ss * (TL_KC * 2), st + TL_PLANE + wave * 1024);
-        tl_dma1k(w_src + (int64_t)ss * 4096, st + 2 * TL_PLANE + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < S::WPIECES; i++) tl_dma1k(w_src[i] + (int64_t)ss * 4096, st + 2 * TL_PLANE + (wave + i * S::WAVES) * 1024);
     };
 
     // ---- epilogue operands: requested before the copies (they are older than every copy in the wave's queue, so the counted waits below cover them) ----
@@ -105,16 +122,21 @@ __global__ __launch_bounds__(1024) void k_tall(TallArgs a) {
         if (a.R) e_r = *reinterpret_cast<const float4*>(a.R + mc * a.ldr + nc);
     }
 
-    if (nch > 0) issue(0);
-    if (nch > 1) issue(1);
+#pragma unroll
+    for (int c = 0; c < TL_NS - 1; c++) if (c < nch) issue(c);
     tl_f32x4 acc_h = {0.f, 0.f, 0.f, 0.f}, acc_l = {0.f, 0.f, 0.f, 0.f};
     const int x_off = (rt * 16 + i16) * 256, x_swz = tl_swz(i16);
     for (int ch = 0; ch < nch; ch++) {
-        // chunk ch has landed: this wave's three copies of it (everything but the three youngest -- chunk ch + 1's -- is complete), then everybody's
-        if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // ... which also says that every wave has finished reading chunk ch - 1: its stage takes chunk ch + 2
-        if (ch + 2 < nch) issue(ch + 2);
+        // chunk ch has landed: this wave's copies of it (everything but the copies of the chunks issued after it -- up to NS - 2 of them -- is complete), then everybody's
+        switch (min(TL_NS - 2, nch - 1 - ch) * S::PIECES) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        }
+        __syncthreads();   // ... which also says that every wave has finished reading chunk ch - 1: its stage takes chunk ch + NS - 1
+        if (ch + TL_NS - 1 < nch) issue(ch + TL_NS - 1);
         const char* st = lds + (ch % TL_NS) * TL_STAGE;
 #pragma unroll
         for (int s = 0; s < 4; s++) {
@@ -172,9 +194,15 @@ bool tall_supported(const TallArgs& a) {
 
 void launch_tall(const TallArgs& a, hipStream_t stream) {
     note_launch("k_tall");
-    const dim3 grid((unsigned)((a.N + TL_COLS - 1) / TL_COLS), (unsigned)((a.M + TL_ROWS - 1) / TL_ROWS), (unsigned)std::max(1, a.splitk));
-    if (a.ch) hipLaunchKernelGGL(k_tall<true>, grid, dim3(1024), 0, stream, a);
-    else hipLaunchKernelGGL(k_tall<false>, grid, dim3(1024), 0, stream, a);
+    const int rows = a.M <= 128 ? 32 : 64;
+    const dim3 grid((unsigned)((a.N + TL_COLS - 1) / TL_COLS), (unsigned)((a.M + rows - 1) / rows), (unsigned)std::max(1, a.splitk));
+    if (rows == 32) {
+        if (a.ch) hipLaunchKernelGGL((k_tall<true, 32>), grid, dim3(512), 0, stream, a);
+        else hipLaunchKernelGGL((k_tall<false, 32>), grid, dim3(512), 0, stream, a);
+    } else {
+        if (a.ch) hipLaunchKernelGGL((k_tall<true, 64>), grid, dim3(1024), 0, stream, a);
+        else hipLaunchKernelGGL((k_tall<false, 64>), grid, dim3(1024), 0, stream, a);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

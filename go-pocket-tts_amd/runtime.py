@@ -107,7 +107,7 @@ ABI_SYMBOLS = [
 # the test / measurement hooks of include/ptts_debug.h: exported by libptts_hooks.so, never by libptts_hip.so (checked by __graft_entry__.build())
 HOOK_SYMBOLS = [
     "ptts_decode_stages", "ptts_mimi_layer_piece", "ptts_debug_last_attention_kernel", "ptts_debug_launch_counts", "ptts_debug_flow_cluster_inject",
-    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps",
+    "ptts_debug_time_skinny", "ptts_debug_skinny_stamps", "ptts_debug_gemm", "ptts_debug_step_stamps", "ptts_debug_tall_linear",
 ]
 
 
@@ -864,6 +864,33 @@ def op_attention_positions(q, k, v, posq, posk, context: int) -> np.ndarray:
     out = np.empty((b, h, tq, d), np.float32)
     _check(lib().ptts_op_attention_positions(_fp(q), _fp(k), _fp(v), b, h, tq, tk, d, _ip(pq), _ip(pk), context, _fp(out)))
     return out
+
+
+def debug_tall_linear(x, w, *, bias=None, residual=None, epi=0, splitk=1, ln=None, planes=None, pbias=None, out_planes=False):
+    """The AR step's 128+-row linear (csrc/tall.hip) on host operands (ptts_debug_tall_linear): `ln` = (weight, bias, eps) sends the rows through k_rowprep
+    (with `planes` [psplit, M, K] and `pbias` summed in first); returns (out [splitk or 1, M, N] squeezed, updated rows or None)."""
+    x, w = _f32(x), _f32(w)
+    m, k = x.shape
+    n = w.shape[0]
+    s = max(1, int(splitk))
+    out = np.empty((s, m, n), np.float32)
+    lw = lb = None
+    eps = 1e-5
+    if ln is not None:
+        lw, lb, eps = _f32(ln[0]), _f32(ln[1]), float(ln[2])
+    pl = _f32(planes) if planes is not None else None
+    pb = _f32(pbias) if pbias is not None else None
+    b = _f32(bias) if bias is not None else None
+    r = _f32(residual) if residual is not None else None
+    xo = np.empty((m, k), np.float32) if (pl is not None and ln is not None) else None
+    nul = C.cast(None, _FP)
+    H = hooks()
+    H.ptts_debug_tall_linear.argtypes = [C.c_int32] * 5 + [_FP, _FP, C.c_int32, _FP, _FP, _FP, C.c_float, _FP, _FP, _FP, C.c_int32, _FP, _FP]
+    _check(H.ptts_debug_tall_linear(m, n, k, int(epi), s, _fp(x), _fp(pl) if pl is not None else nul, 0 if pl is None else pl.shape[0],
+                                    _fp(pb) if pb is not None else nul, _fp(lw) if lw is not None else nul, _fp(lb) if lb is not None else nul, eps,
+                                    _fp(w), _fp(b) if b is not None else nul, _fp(r) if r is not None else nul, 1 if out_planes else 0, _fp(out),
+                                    _fp(xo) if xo is not None else nul))
+    return (out[0] if s == 1 else out), xo
 
 
 def last_attention_kernel() -> str:

@@ -37,6 +37,15 @@ int ptts_debug_step_stamps(ptts_batch* b, int32_t lsd_steps, uint64_t* out /* [c
 int ptts_debug_gemm(int32_t M, int32_t N, int32_t K, int32_t w_bf16, int32_t variant, int32_t epi, int32_t iters, float* avg_us,
                     float* maxdiff);
 
+/* The AR step's linears at 128+ rows (csrc/tall.hip), stand-alone on host operands: with ln_w the rows go through k_rowprep first (x' = x + sum of the
+ * `psplit` planes [psplit][M][K] + pbias -> x_out; LayerNorm(x') -> bf16 hi / lo planes), without it x is split on the host; then
+ * out = epi(A W^T + bias) by k_tall (W [N][K] row-major, rounded to bf16 by the hook; epi 0 none, 1 GELU, 4 residual add of R [M][N]); splitk > 1: `out`
+ * receives the planes [splitk][M][N] (plane 0 carries R + bias); out_planes: the result leaves through the bf16 hi / lo planes the next product reads
+ * (hi + lo is returned). */
+int ptts_debug_tall_linear(int32_t M, int32_t N, int32_t K, int32_t epi, int32_t splitk, const float* x, const float* planes, int32_t psplit, const float* pbias,
+                           const float* ln_w, const float* ln_b, float eps, const float* W, const float* bias, const float* R, int32_t out_planes, float* out,
+                           float* x_out);
+
 /* name of the kernel the calling thread's last attention launch used ("k_attn_step", "k_attn_window", "k_attn_window<ragged>",
  * "k_attention"): lets a parity test assert that it exercised the kernel it means to */
 const char* ptts_debug_last_attention_kernel(void);

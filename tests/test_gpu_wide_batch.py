@@ -1,6 +1,7 @@
-"""More than 64 rows per AR step (round 5): the step's kernels take up to 256 utterances -- row tiles of the step linear (k_skinny, blockIdx.y),
-one workgroup per (utterance, head) in the step attention, 12-row tiles of the flow-net cluster (k_flow_cluster), the decoder in groups of 64
-utterances through one workspace.  The reference is batch 1 (flow_lm.go:281; internal/native/flow_transformer.go:326-389 is the layer a row goes
+"""More than 64 rows per AR step (round 5): the step's kernels take up to 256 utterances -- row tiles of the step linear (k_skinny, blockIdx.y; from
+128 rows the layer's in_proj / linear1 / linear2 as 32- or 64-row tiles of k_tall behind k_rowprep, csrc/tall.hip -- value by value in
+tests/test_gpu_tall.py), one workgroup per (utterance, head) in the step attention, 12-row tiles of the flow-net cluster (k_flow_cluster), the decoder in
+groups of 64 utterances through one workspace.  The reference is batch 1 (flow_lm.go:281; internal/native/flow_transformer.go:326-389 is the layer a row goes
 through); its counterpart of "how many at once" is the server's worker count (internal/server/server.go:132-134).  A wider batch must not change
 what a row computes: the tests are the ones tests/test_gpu_fullsize.py runs at 64 rows -- teacher-forced against the oracle over the full 125
 steps, slot symmetry bit for bit, graph replay == plain launches -- at 128 rows, and the size-independent properties at 256.

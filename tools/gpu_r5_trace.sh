@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: kernel trace of the one-shot probe at the batch sizes in $2 (default 128,256), by-grid summary; then the MFMA hazard probe.  usage: tools/gpu_r5_trace.sh TAG [BATCHES]
+# GPU box: kernel trace of the one-shot probe at the batch sizes in $2 (default 128,256), by-grid summary.  usage: tools/gpu_r5_trace.sh TAG [BATCHES]
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
 tag=${1:-r5trace}; sizes=${2:-128,256}
 for B in ${sizes//,/ }; do
@@ -9,7 +9,3 @@ for B in ${sizes//,/ }; do
   rm -rf gpurun_out/${tag}_prof$B
   echo "== B=$B"; head -42 gpurun_out/${tag}_by_grid_b$B.txt
 done
-if [ -x tools/probes/mfma_hazard/build/probe ]; then
-  timeout -k 10 300 tools/probes/mfma_hazard/build/probe > gpurun_out/${tag}_mfma_hazard.txt 2>&1; echo "hazard probe rc=$?"
-  grep -c "bad=0" gpurun_out/${tag}_mfma_hazard.txt; grep -v "bad=0" gpurun_out/${tag}_mfma_hazard.txt | head -60
-fi
