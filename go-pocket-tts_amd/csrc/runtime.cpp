@@ -845,7 +845,21 @@ bool step_core(Batch& b, int lsd, bool opened, bool fuse_finish, bool chain) {
         fu.partial = pend.partial; fu.psplit = pend.splitk; fu.pstride = pend.pstride; fu.pbias = pend.bias;
         fu.ln = 1; fu.eps = in.eps; fu.ln_w = m.at<float>(d.out_norm.w); fu.ln_b = m.at<float>(d.out_norm.b);
         tail_fused = skinny_fuse_supported(g1, fu) && skinny_fuse_supported(g2, fu);
-        if (tail_fused) {
+        if (tall && d.cond_eos.wt != NONE) {
+            // 128 rows and more: the pending sum and out_norm once per row (k_rowprep writes `last`); [cond_embed ; out_eos] then reads finished rows -- every
+            // block of the fused form would redo the four-plane prologue (16.3 us at 256 rows against 4.7 + 8)
+            PrepArgs pa;
+            pa.x = xin; pa.ldx = D; pa.partial = pend.partial; pa.psplit = pend.splitk; pa.pstride = pend.pstride; pa.pbias = pend.bias;
+            pa.x_out = pend.partial ? x : nullptr;
+            pa.ln_w = m.at<float>(d.out_norm.w); pa.ln_b = m.at<float>(d.out_norm.b); pa.eps = d.out_norm.eps;
+            pa.yh = pa_h; pa.yl = pa_l; pa.ldy = D; pa.y_out = last; pa.M = B; pa.D = D;
+            if (!rowprep_supported(pa)) throw Error(PTTS_EINVAL, "ptts-hip: internal: shape not supported by the row preparation kernel");
+            launch_rowprep(pa, s);
+            GemmArgs g = mk(m, last, flat(D), d.cond_eos, sy, flat(C), B);
+            g.epi = EPI_SILU; g.addvec = tc; g.tail = b.eos.as<float>();
+            step_gemm(m, g);
+            tail_fused = true;
+        } else if (tail_fused) {
             in.y_out = last;
             if (d.cond_eos.wt != NONE) {   // one launch: columns 0..C-1 = cond_embed (SiLU epilogue), column C = out_eos (raw)
                 GemmArgs g = mk(m, xin, flat(D), d.cond_eos, sy, flat(C), B);
