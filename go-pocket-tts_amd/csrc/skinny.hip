@@ -639,8 +639,10 @@ template <int WBF16, int PRO, int NJ>
 static void launch_nj(const GemmArgs& a, const SkinnyFuse& fu, int splitk, float* partial, dim3 /*grid*/, hipStream_t stream) {
     // narrow blocks when the 64-column grid would occupy fewer than half of the 256 CUs
     const int blocks64 = ((a.N + 63) / 64) * ((a.M + 15) / 16) * splitk;
-    const int blocks16 = ((a.N + 15) / 16) * ((a.M + 15) / 16) * splitk;   // ... unless the narrow grid then needs a second round of CUs (513 columns x 128 rows: 264 blocks)
-    if (blocks64 < 128 && blocks16 <= 256 && a.N > 16 && !fu.fin) launch_cg<WBF16, PRO, NJ, 1>(a, fu, splitk, partial, stream);   // fin: one column block (see SkinnyFuse)
+    // ... unless, beyond 64 rows, the narrow grid then needs a second round of CUs (513 columns x 128 rows: 264 blocks).  Up to 64 rows the choice stays what it
+    // was: the K parts a wave sums (the rounding order) follow it, and a continuous engine's packed prefill must give a prompt the bits its stand-alone prefill gives
+    const int blocks16 = ((a.N + 15) / 16) * ((a.M + 15) / 16) * splitk;
+    if (blocks64 < 128 && (a.M <= 64 || blocks16 <= 256) && a.N > 16 && !fu.fin) launch_cg<WBF16, PRO, NJ, 1>(a, fu, splitk, partial, stream);   // fin: one column block (see SkinnyFuse)
     else launch_cg<WBF16, PRO, NJ, 4>(a, fu, splitk, partial, stream);
 }
 
