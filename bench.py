@@ -232,29 +232,42 @@ def gen_cfgs(pkg, wl, n, voice, **kw):
     return [pkg.RuntimeGenerateConfig(**base) for _ in range(n)]
 
 
+def two_barrier_pass(barrier, sync, prepare, timed):
+    """prepare() builds and warms (untimed), timed() is the measured round; returns (wall seconds of timed(), the exception or None).  EVERY rank reaches both
+    barriers whatever happens on it -- a rank whose engine failed must not leave the others waiting inside a collective."""
+    err, dt = None, 0.0
+    try:
+        prepare()
+    except Exception as e:  # noqa: BLE001
+        err = e
+    sync(); barrier()
+    if err is None:
+        try:
+            t0 = time.perf_counter()
+            timed()
+            sync()
+            dt = time.perf_counter() - t0
+        except Exception as e:  # noqa: BLE001
+            err = e
+    barrier()
+    return dt, err
+
+
 def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_client=2):
     """BASELINE.json configs[3] names the serve-mode worker pool (internal/server/server.go:119-143,398-421): this rank's share of it is one
     dispatcher over two engines of its GPU (one weight arena), fed by closed-loop clients that each synthesise 10-s utterances back to back
     (64 per engine in flight).  Returns (audio seconds, wall seconds, p50 latency) of the timed rounds; an untimed round comes first."""
     import threading
-    m2 = model.share()
-    for m in (model, m2):
-        m.set_use_graph(False)   # plain launches: the dispatcher's default, and no idle gap between replays when two engines interleave
-    cfg = gen_cfgs(pkg, wl, 1, voice, pcm16=True)[0]
-    toks = [p.tolist() for p in prompts]
-    # every engine once at full batch before anything is timed: an engine's first call allocates its KV caches, ~16 GB of decoder workspace and its share of
-    # the page-locked result pool (~0.5 s) -- the untimed round below does not always reach both engines (its two batches may land on the same one), and an
-    # engine first used inside the timed rounds then costs half a second of them (seen once: 2.3 k instead of 15.9 k x real time)
-    for m in (model, m2):
-        m.generate_batch(toks[:wl["batch"]], [cfg] * min(wl["batch"], len(toks)))
-    disp = pkg.Dispatcher([model, m2], max_batch=wl["batch"], window_us=3000)
+    st = {"m2": None, "disp": None}
     lat = []
     lock = threading.Lock()
+    cfg = gen_cfgs(pkg, wl, 1, voice, pcm16=True)[0]
+    toks = [p.tolist() for p in prompts]
 
     def client(i, n):
         for k in range(n):
             t0 = time.perf_counter()
-            r = disp.generate(toks[(i + k) % len(toks)], cfg)
+            r = st["disp"].generate(toks[(i + k) % len(toks)], cfg)
             with lock:
                 lat.append(time.perf_counter() - t0)
             assert r.n_frames == wl["frames"]
@@ -264,73 +277,87 @@ def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_c
         [t.start() for t in ts]
         [t.join() for t in ts]
 
-    round_(1)
-    lat.clear()
-    sync(); barrier()
-    t0 = time.perf_counter()
-    round_(per_client)
-    sync()
-    dt = time.perf_counter() - t0
-    barrier()
-    st = disp.stats()
-    disp.close()
-    m2.close()
-    model.set_use_graph(True)
-    return clients * per_client * wl["frames"] * FRAME_SEC, dt, statistics.median(lat), st["mean_batch"]
+    def prepare():
+        st["m2"] = m2 = model.share()
+        for m in (model, m2):
+            m.set_use_graph(False)   # plain launches: the dispatcher's default, and no idle gap between replays when two engines interleave
+        # every engine once at full batch before anything is timed: an engine's first call allocates its KV caches, ~16 GB of decoder workspace and its share of
+        # the page-locked result pool (~0.5 s) -- the untimed round below does not always reach both engines (its two batches may land on the same one), and an
+        # engine first used inside the timed rounds then costs half a second of them (seen once: 2.3 k instead of 15.9 k x real time)
+        for m in (model, m2):
+            m.generate_batch(toks[:wl["batch"]], [cfg] * min(wl["batch"], len(toks)))
+        st["disp"] = pkg.Dispatcher([model, m2], max_batch=wl["batch"], window_us=3000)
+        round_(1)
+        lat.clear()
+
+    try:
+        dt, err = two_barrier_pass(barrier, sync, prepare, lambda: round_(per_client))
+        if err is not None:
+            raise err
+        mean_batch = st["disp"].stats()["mean_batch"]
+    finally:
+        if st["disp"] is not None:
+            st["disp"].close()
+        if st["m2"] is not None:
+            st["m2"].close()
+        model.set_use_graph(True)
+    return clients * per_client * wl["frames"] * FRAME_SEC, dt, statistics.median(lat), mean_batch
 
 
-def serve_mixed_pass(pkg, model, wl, voice, barrier, sync, slots=192, clients=384, per_client=2):
+def serve_mixed_pass(pkg, model, wl, voice, barrier, sync, slots=192, clients=384, per_client=4):
     """The serving leg on what real traffic looks like once EOS is finite: utterances of 2-12 s (budgets drawn uniformly from 25..150 frames per request)
     through ONE continuous-batching engine of `slots` utterances (csrc/continuous.cpp: slots refilled between groups of AR steps, finished utterances decoded
     beside the following steps; internal/server/server.go:398-421 + internal/tts/service.go:138-153 are the reference's counterparts), closed-loop clients.
-    Returns (audio seconds, wall seconds, p50 latency, mean occupied slots) of the timed round."""
+    Returns (audio seconds, wall seconds, p50 latency, mean occupied slots, flow-cluster fallbacks) of the timed round."""
     import random
     import threading
-    eng = model.share()
-    try:
+    st = {"eng": None, "disp": None, "st0": None}
+    prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
+    plan = random.Random(5)
+    frames = [plan.randint(25, 150) for _ in range(4096)]
+    lat, done = [], []
+    lock = threading.Lock()
+
+    def client(i, n):
+        for k in range(n):
+            nf = frames[(i * per_client + k) % len(frames)]
+            c = pkg.RuntimeGenerateConfig(temperature=0.0, eos_threshold=float("inf"), max_steps=nf, lsd_decode_steps=1, frames_after_eos=3, device_voice=voice, pcm16=True)
+            t0 = time.perf_counter()
+            r = st["disp"].generate(prompts[(i * per_client + k) % len(prompts)], c)
+            dt = time.perf_counter() - t0
+            assert r.n_frames == nf
+            with lock:
+                lat.append(dt)
+                done.append(nf)
+
+    def round_(n):
+        ts = [threading.Thread(target=client, args=(i, n)) for i in range(clients)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+
+    def prepare():
+        st["eng"] = eng = model.share()
         eng.set_max_batch(slots)
         eng.set_use_graph(False)
-        prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
         warm = gen_cfgs(pkg, wl, 1, voice, pcm16=True)[0]
         eng.generate_batch(prompts[:slots], [warm] * slots)     # the engine's buffers (KV caches at this width, result pool) exist before anything is timed
-        plan = random.Random(5)
-        frames = [plan.randint(25, 150) for _ in range(4096)]
-        disp = pkg.Dispatcher([eng], max_batch=slots, window_us=3000, continuous=True, cont_kv_capacity=512, cont_max_steps=256)
-        lat, done = [], []
-        lock = threading.Lock()
-
-        def client(i, n):
-            for k in range(n):
-                nf = frames[(i * per_client + k) % len(frames)]
-                c = pkg.RuntimeGenerateConfig(temperature=0.0, eos_threshold=float("inf"), max_steps=nf, lsd_decode_steps=1, frames_after_eos=3, device_voice=voice, pcm16=True)
-                t0 = time.perf_counter()
-                r = disp.generate(prompts[(i * per_client + k) % len(prompts)], c)
-                dt = time.perf_counter() - t0
-                assert r.n_frames == nf
-                with lock:
-                    lat.append(dt)
-                    done.append(nf)
-
-        def round_(n):
-            ts = [threading.Thread(target=client, args=(i, n)) for i in range(clients)]
-            [t.start() for t in ts]
-            [t.join() for t in ts]
-
+        st["disp"] = pkg.Dispatcher([eng], max_batch=slots, window_us=3000, continuous=True, cont_kv_capacity=512, cont_max_steps=256)
         round_(1)
         lat.clear(); done.clear()
-        st0 = disp.stats()
-        sync(); barrier()
-        t0 = time.perf_counter()
-        round_(per_client)
-        sync()
-        dt = time.perf_counter() - t0
-        barrier()
-        st = disp.stats()
-        disp.close()
-        occ = (st["cont_slot_steps"] - st0["cont_slot_steps"]) / max(1, st["cont_steps"] - st0["cont_steps"])
-        return sum(done) * FRAME_SEC, dt, statistics.median(lat), occ, st["flow_cluster_fallbacks"]
+        st["st0"] = st["disp"].stats()
+
+    try:
+        dt, err = two_barrier_pass(barrier, sync, prepare, lambda: round_(per_client))
+        if err is not None:
+            raise err
+        s1, s0 = st["disp"].stats(), st["st0"]
+        occ = (s1["cont_slot_steps"] - s0["cont_slot_steps"]) / max(1, s1["cont_steps"] - s0["cont_steps"])
+        return sum(done) * FRAME_SEC, dt, statistics.median(lat), occ, s1["flow_cluster_fallbacks"]
     finally:
-        eng.close()
+        if st["disp"] is not None:
+            st["disp"].close()
+        if st["eng"] is not None:
+            st["eng"].close()
 
 
 def run_workload(pkg, model, wl, prompts, voice, steps, warmup, barrier, sync, **cfg_kw):
@@ -719,26 +746,36 @@ def main():
     if not args.no_two_engines and args.workload == "b64_10s_bf16":
         # every rank, its own GPU: the serve-mode shape of configs[3] (per-GPU shard of the worker pool); aggregate = sum of the ranks' audio
         # over the slowest rank's wall time, like `value`
+        # (a pass that fails on ONE rank must not leave the others waiting in a collective: every rank runs the pass on its own, then all of them agree on
+        # whether it succeeded everywhere before any aggregate is formed)
+        def everywhere(ok: bool) -> bool:
+            return max_over_ranks(0.0 if ok else 1.0, world, dev) == 0.0
         try:
-            a_s, dt_s, p50_s, mb_s = serve_pass(pkg, model, wl, prompts, voice, barrier, sync)
+            sp = serve_pass(pkg, model, wl, prompts, voice, barrier, sync)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] serve-mode pass failed on rank {rank}: {e}")
+            sp = None
+        if everywhere(sp is not None):
+            a_s, dt_s, p50_s, mb_s = sp
             dt_all = max_over_ranks(dt_s, world, dev)
             result["serve_mode"] = {"value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
                                     "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
                                     "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 2 "
                                               f"requests of {wl['frames']} frames, PCM16; {world} GPU(s), no exchange between them"}
-        except Exception as e:  # noqa: BLE001
-            log(f"[bench] serve-mode pass failed: {e}")
         try:
-            a_m, dt_m, p50_m, occ_m, fb_m = serve_mixed_pass(pkg, model, wl, voice, barrier, sync)
+            mp = serve_mixed_pass(pkg, model, wl, voice, barrier, sync)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] mixed-length serve pass failed on rank {rank}: {e}")
+            mp = None
+        if everywhere(mp is not None):
+            a_m, dt_m, p50_m, occ_m, fb_m = mp
             dt_all = max_over_ranks(dt_m, world, dev)
             a_all = sum(gather_over_ranks(a_m, world, dev))
             result.setdefault("serve_mode", {})["mixed_continuous"] = {
                 "value": round(a_all / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_m, 1),
                 "per_rank_xrt": [round(x / dt_all, 1) for x in gather_over_ranks(a_m, world, dev)], "mean_occupied_slots": round(occ_m, 1), "flow_cluster_fallbacks": fb_m,
-                "config": f"per GPU: one continuous-batching engine of 192 slots (ptts_dispatch_opts.continuous), 384 closed-loop clients x 2 requests of 25..150 frames "
+                "config": f"per GPU: one continuous-batching engine of 192 slots (ptts_dispatch_opts.continuous), 384 closed-loop clients x 4 requests of 25..150 frames "
                           f"(2-12 s, uniformly drawn), PCM16; {world} GPU(s), no exchange between them"}
-        except Exception as e:  # noqa: BLE001
-            log(f"[bench] mixed-length serve pass failed: {e}")
     if rank == 0:
         try:
             result["roofline"] = roofline_pass(pkg, model, wl, prompts, voice, traffic)

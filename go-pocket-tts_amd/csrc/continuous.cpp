@@ -380,7 +380,11 @@ static void activate_ready(ContEngine& e, bool wait) {
             if (q == hipErrorNotReady) {
                 // the prefill is still running beside the group in flight: the step STREAM waits for it (in front of the next group) rather than the host
                 // looking again a group later -- a newcomer idles one group less, at the price of a short stall of everyone when the prefill is the slower
-                // (waiting a group instead: occupancy 54.5 -> 58 of 64 slots with it, +3..5 % throughput)
+                // (waiting a group instead: occupancy 54.5 -> 58 of 64 slots with it, +3..5 % throughput).  The prefill stream is the model's second one, created
+                // with the LOW priority (its one-shot job is the decoder behind the AR loop); a stream of its own at the step chain's priority would be the
+                // engine's fourth, which measured 6.1 k x instead of 10.9 k (cont_create) -- the stall is bounded by one prefill (0.3-1.2 ms), not by the decoder's
+                // queue.  The wait binds to the record made BEFORE this call (hipStreamWaitEvent captures the event's current record): handing j.ready back to
+                // free_events below, and recording it again for a later prefill, does not move this wait.
                 PTTS_HIP(hipStreamWaitEvent(e.m.stream, j.ready, 0));
             } else if (q != hipSuccess) throw Error(PTTS_ENODEVICE, strfmt("hip: hipEventQuery failed: %s", hipGetErrorString(q)));
         }

@@ -96,3 +96,28 @@ def test_bench_refuses_a_rank_count_that_disagrees_with_the_launcher():
     env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=120, env=env)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_a_serve_pass_that_fails_on_one_rank_still_reaches_both_barriers():
+    """bench.py's serve legs run on every rank between two barriers; a rank whose engine fails (prepare or the timed round) must reach both anyway, or the
+    other ranks wait in the collective for ever (bench.two_barrier_pass)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for fail_in in (None, "prepare", "timed"):
+        calls = []
+
+        def prepare():
+            calls.append("prepare")
+            if fail_in == "prepare":
+                raise RuntimeError("engine did not come up")
+
+        def timed():
+            calls.append("timed")
+            if fail_in == "timed":
+                raise RuntimeError("a client failed")
+
+        dt, err = bench.two_barrier_pass(lambda: calls.append("barrier"), lambda: calls.append("sync"), prepare, timed)
+        assert calls.count("barrier") == 2, (fail_in, calls)
+        assert (err is None) == (fail_in is None)
+        assert ("timed" in calls) == (fail_in != "prepare")        # nothing is timed on a rank whose preparation failed
+        assert calls[-1] == "barrier"
