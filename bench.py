@@ -304,17 +304,18 @@ def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_c
     return clients * per_client * wl["frames"] * FRAME_SEC, dt, statistics.median(lat), mean_batch
 
 
-def serve_mixed_pass(pkg, model, wl, voice, barrier, sync, slots=192, clients=384, per_client=4):
-    """The serving leg on what real traffic looks like once EOS is finite: utterances of 2-12 s (budgets drawn uniformly from 25..150 frames per request)
-    through ONE continuous-batching engine of `slots` utterances (csrc/continuous.cpp: slots refilled between groups of AR steps, finished utterances decoded
-    beside the following steps; internal/server/server.go:398-421 + internal/tts/service.go:138-153 are the reference's counterparts), closed-loop clients.
+def serve_continuous_pass(pkg, model, wl, voice, barrier, sync, slots=192, clients=384, per_client=4, mixed=True):
+    """The serving legs through the dispatcher's DEFAULT configuration for one model on its GPU: ONE continuous-batching engine of `slots` utterances
+    (csrc/continuous.cpp: slots refilled between groups of AR steps, finished utterances decoded beside -- or, a wave of them, between -- the following steps;
+    internal/server/server.go:398-421 + internal/tts/service.go:138-153 are the reference's counterparts), closed-loop clients.  mixed: what real traffic looks
+    like once EOS is finite -- utterances of 2-12 s (budgets drawn uniformly from 25..150 frames per request); else every request is the workload's 10 s.
     Returns (audio seconds, wall seconds, p50 latency, mean occupied slots, flow-cluster fallbacks) of the timed round."""
     import random
     import threading
     st = {"eng": None, "disp": None, "st0": None}
     prompts = [p.tolist() for p in pkg.synth.make_prompts(256, 25, 4000, seed=3)]
     plan = random.Random(5)
-    frames = [plan.randint(25, 150) for _ in range(4096)]
+    frames = [plan.randint(25, 150) if mixed else wl["frames"] for _ in range(4096)]
     lat, done = [], []
     lock = threading.Lock()
 
@@ -341,7 +342,7 @@ def serve_mixed_pass(pkg, model, wl, voice, barrier, sync, slots=192, clients=38
         eng.set_use_graph(False)
         warm = gen_cfgs(pkg, wl, 1, voice, pcm16=True)[0]
         eng.generate_batch(prompts[:slots], [warm] * slots)     # the engine's buffers (KV caches at this width, result pool) exist before anything is timed
-        st["disp"] = pkg.Dispatcher([eng], max_batch=slots, window_us=3000, continuous=True, cont_kv_capacity=512, cont_max_steps=256)
+        st["disp"] = pkg.Dispatcher([eng], max_batch=slots, window_us=3000)   # the default: continuous batching (one model alone on its GPU), 512 keys, 256 steps
         round_(1)
         lat.clear(); done.clear()
         st["st0"] = st["disp"].stats()
@@ -750,32 +751,41 @@ def main():
         # whether it succeeded everywhere before any aggregate is formed)
         def everywhere(ok: bool) -> bool:
             return max_over_ranks(0.0 if ok else 1.0, world, dev) == 0.0
+        serve = {}
+        for key, kw, what in (("uniform", dict(slots=256, clients=512, per_client=4, mixed=False), f"512 closed-loop clients x 4 requests of {wl['frames']} frames"),
+                              ("mixed_continuous", dict(slots=192, clients=384, per_client=4, mixed=True),
+                               "384 closed-loop clients x 4 requests of 25..150 frames (2-12 s, uniformly drawn)")):
+            try:
+                cp = serve_continuous_pass(pkg, model, wl, voice, barrier, sync, **kw)
+            except Exception as e:  # noqa: BLE001
+                log(f"[bench] serve pass '{key}' failed on rank {rank}: {e}")
+                cp = None
+            if everywhere(cp is not None):
+                a_m, dt_m, p50_m, occ_m, fb_m = cp
+                dt_all = max_over_ranks(dt_m, world, dev)
+                a_all = sum(gather_over_ranks(a_m, world, dev))
+                serve[key] = {
+                    "value": round(a_all / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_m, 1),
+                    "per_rank_xrt": [round(x / dt_all, 1) for x in gather_over_ranks(a_m, world, dev)], "mean_occupied_slots": round(occ_m, 1), "flow_cluster_fallbacks": fb_m,
+                    "config": f"per GPU: the dispatcher's default for one model on its GPU -- one continuous-batching engine, {kw['slots']} slots; {what}, PCM16; "
+                              f"{world} GPU(s), no exchange between them"}
         try:
             sp = serve_pass(pkg, model, wl, prompts, voice, barrier, sync)
         except Exception as e:  # noqa: BLE001
-            log(f"[bench] serve-mode pass failed on rank {rank}: {e}")
+            log(f"[bench] two-engine serve pass failed on rank {rank}: {e}")
             sp = None
         if everywhere(sp is not None):
             a_s, dt_s, p50_s, mb_s = sp
             dt_all = max_over_ranks(dt_s, world, dev)
-            result["serve_mode"] = {"value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
-                                    "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
-                                    "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 2 "
-                                              f"requests of {wl['frames']} frames, PCM16; {world} GPU(s), no exchange between them"}
-        try:
-            mp = serve_mixed_pass(pkg, model, wl, voice, barrier, sync)
-        except Exception as e:  # noqa: BLE001
-            log(f"[bench] mixed-length serve pass failed on rank {rank}: {e}")
-            mp = None
-        if everywhere(mp is not None):
-            a_m, dt_m, p50_m, occ_m, fb_m = mp
-            dt_all = max_over_ranks(dt_m, world, dev)
-            a_all = sum(gather_over_ranks(a_m, world, dev))
-            result.setdefault("serve_mode", {})["mixed_continuous"] = {
-                "value": round(a_all / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_m, 1),
-                "per_rank_xrt": [round(x / dt_all, 1) for x in gather_over_ranks(a_m, world, dev)], "mean_occupied_slots": round(occ_m, 1), "flow_cluster_fallbacks": fb_m,
-                "config": f"per GPU: one continuous-batching engine of 192 slots (ptts_dispatch_opts.continuous), 384 closed-loop clients x 4 requests of 25..150 frames "
-                          f"(2-12 s, uniformly drawn), PCM16; {world} GPU(s), no exchange between them"}
+            serve["two_engines_batch_at_a_time"] = {
+                "value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
+                "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
+                "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 2 "
+                          f"requests of {wl['frames']} frames, PCM16 (rounds 2-4's serve_mode figure); {world} GPU(s)"}
+        if "uniform" in serve:   # serve_mode = uniform traffic through the default configuration; the other legs beside it
+            result["serve_mode"] = dict(serve.pop("uniform"), **serve)
+        elif serve:
+            result["serve_mode"] = serve
     if rank == 0:
         try:
             result["roofline"] = roofline_pass(pkg, model, wl, prompts, voice, traffic)

@@ -36,6 +36,7 @@ namespace {
 // 128-256 slots (profiles/r5_serve_sweep.txt: decodes of 16 / 32 / 48 utterances alike; 85 / 96 CUs for the decoder -12..-30 %, 160 / 256 CUs -3..-5 %):
 constexpr int kDecoderShare = 2;      // the decoder's stream gets 1 / kDecoderShare of the device's CUs (128 of the MI355X's 256): see cont_create
 constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
+constexpr int kDecodeSerialFrames = 2400;   // finished utterances with this many frames between them (a cluster of long, like-length requests ending together) are decoded IN the step chain, on the whole chip: see start_decode
 constexpr int kDecodeMaxAge = 8;      // ... or the oldest has waited this many groups of steps (a caller waiting for audio is a caller not sending its next request)
 constexpr int kBandFrames = 16, kBandPercent = 16;   // a decode pads everything to its longest member: members within max(16 frames, 16 %) of it
 
@@ -405,7 +406,16 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
     const Desc& d = m.d;
     const int ld = d.ldim;
     const int64_t spf = d.samples_per_frame;
-    hipStream_t s = m.stream, s2 = e.dec;
+    // Where the decode runs.  A handful of finished utterances (mixed lengths: ~16 at a time) goes to the confined stream BESIDE the following steps: such a decode
+    // cannot fill the chip anyway and the steps it slows by 1.4-2 x are few.  A WAVE of them (uniform traffic: a whole engine's worth ends within a group or two) is
+    // several full-chip decodes' worth of work; beside it every step would run on half of the CUs for its whole length -- it is queued in the step chain instead, on
+    // all CUs, and the steps resume at full speed behind it (256 slots, uniform 10-s requests: 17.8 k -> 20.0 k x; mixed 2-12 s through the same rule: unchanged,
+    // always-serial 14.6 k -> 12.5 k x; profiles/r5_serve_sweep.txt).
+    static const int serial_frames = [] { const char* v = getenv("PTTS_CONT_SERIAL_FRAMES"); return v ? atoi(v) : kDecodeSerialFrames; }();
+    int64_t fin_frames = 0;
+    for (const ContEngine::Staged& f : fin) fin_frames += f.nf;
+    const bool serial = fin_frames >= serial_frames;
+    hipStream_t s = m.stream, s2 = serial ? m.stream : e.dec;
     e.tr_decodes += (int)fin.size();
     std::sort(fin.begin(), fin.end(), [](const ContEngine::Staged& x, const ContEngine::Staged& y) { return x.nf > y.nf; });   // like lengths together: less padding
     // sub-groups whose decode fits the workspace; their frames are gathered FIRST, all of them, and on the AR stream itself: the staging rows are that
@@ -445,8 +455,11 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
                 PTTS_HIP(hipMemcpyAsync(lat_all.as<float>() + sb.off + (i - sb.at) * (size_t)sb.T * ld, e.stage.as<float>() + (size_t)f.row * b.max_steps * ld,
                                         (size_t)f.nf * ld * sizeof(float), hipMemcpyDeviceToDevice, s));
         }
-    PTTS_HIP(hipEventRecord(e.ev_steps, s));
-    PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
+    if (s2 != s) {
+        PTTS_HIP(hipEventRecord(e.ev_steps, s));
+        PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
+    }
+    if (e.lat_busy[lt ^ 1]) PTTS_HIP(hipStreamWaitEvent(s2, e.lat_free[lt ^ 1], 0));   // the previous decode -- possibly on the other stream -- has left the decoder's workspace
     for (const Sub& sb : subs) {
         const size_t at = sb.at, end = sb.end;
         const int T = sb.T;

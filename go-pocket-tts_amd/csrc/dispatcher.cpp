@@ -312,7 +312,17 @@ Dispatcher* dispatcher_create(Model* const* models, int n_models, ExecFn exec, v
     d->max_batch = std::max(1, max_batch <= 0 ? 64 : max_batch);
     d->window_us = std::max(0, window_us);
     d->queue_cap = queue_cap <= 0 ? 4096 : queue_cap;
-    if (cont && cont->on && !exec) {
+    // continuous batching: 1 on, -1 off, 0 the library's choice -- on where it wins both kinds of traffic, i.e. when every model of the dispatcher has its GPU to
+    // itself (one engine per GPU: uniform 10-s requests 19.8 k x against 18.5 k x for the best batch-at-a-time setting, mixed 2-12 s 14.4 k against 10.8 k,
+    // profiles/r5_serve_sweep.txt); two engines sharing a GPU (ptts_model_share) are the batch-at-a-time setting: as continuous engines they would lose to one
+    int on = cont ? cont->on : 0;
+    if (on == 0 && !exec) {
+        on = 1;
+        for (size_t i = 0; i < d->models.size(); i++)
+            for (size_t j = i + 1; j < d->models.size(); j++)
+                if (d->models[i]->device == d->models[j]->device) on = -1;
+    }
+    if (cont && on > 0 && !exec) {
         d->continuous = true;
         if (cont->kv_capacity > 0) d->cont_kv_cap = cont->kv_capacity;
         if (cont->max_steps > 0) d->cont_max_steps = cont->max_steps;

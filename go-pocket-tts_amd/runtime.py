@@ -960,14 +960,14 @@ class Dispatcher:
     semaphore (internal/server/server.go:398-421); concurrent callers are coalesced into batched GenerateAudio passes."""
 
     def __init__(self, models: Sequence[Model], max_batch: int = 0, window_us: int = 2000, queue_cap: int = 0, _custom_exec=None, _workers: int = 1,
-                 continuous: bool = False, cont_kv_capacity: int = 0, cont_max_steps: int = 0, cont_steps_per_group: int = 0):
+                 continuous: Optional[bool] = None, cont_kv_capacity: int = 0, cont_max_steps: int = 0, cont_steps_per_group: int = 0):
         L = lib()
         L.ptts_dispatcher_create.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(_DispatchOpts), C.POINTER(C.c_void_p)]
         L.ptts_dispatcher_create_custom.argtypes = [DISPATCH_EXEC, C.c_void_p, C.c_int32, C.POINTER(_DispatchOpts), C.POINTER(C.c_void_p)]
         L.ptts_dispatch_generate.argtypes = [C.c_void_p, C.POINTER(_Request), C.POINTER(_Result)]
         L.ptts_dispatcher_stats.argtypes = [C.c_void_p, C.POINTER(_DispatchStats)]
         L.ptts_dispatcher_close.argtypes = [C.c_void_p]
-        o = _DispatchOpts(max_batch=max_batch, window_us=window_us, queue_cap=queue_cap, continuous=1 if continuous else 0, cont_kv_capacity=cont_kv_capacity,
+        o = _DispatchOpts(max_batch=max_batch, window_us=window_us, queue_cap=queue_cap, continuous=0 if continuous is None else (1 if continuous else -1), cont_kv_capacity=cont_kv_capacity,
                           cont_max_steps=cont_max_steps, cont_steps_per_group=cont_steps_per_group)
         h = C.c_void_p()
         self.models = list(models)

@@ -251,7 +251,9 @@ typedef struct ptts_dispatch_opts {
     int32_t continuous;   /* 1: continuous batching -- one long-lived batch per model: between groups of AR steps, utterances that have
                            * ended leave for the decoder and waiting requests take their slots (their prompts prefilled as one ragged
                            * launch).  Requests with a step / PCM callback, lsd_steps > 1 or budgets beyond the two limits below run
-                           * batch-at-a-time while the engine is empty.  0: batch-at-a-time for everything */
+                           * batch-at-a-time while the engine is empty.  -1: batch-at-a-time for everything.  0 (the default): continuous
+                           * when every model of the dispatcher has its GPU to itself (where it wins uniform AND mixed-length traffic),
+                           * batch-at-a-time when two of them share one (ptts_model_share: the two-engine setting) */
     int32_t cont_kv_capacity;      /* keys per slot (voice prefix + prompt + steps), <= 0: 512 (the reach of the one-burst step attention with a bf16 cache) */
     int32_t cont_max_steps;        /* step budget per utterance, <= 0: 256 (EstimateMaxFrames of a 50-token chunk is 234) */
     int32_t cont_steps_per_group;  /* AR steps between two looks at the slots, <= 0: 3 */

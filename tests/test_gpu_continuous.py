@@ -324,3 +324,36 @@ def test_a_timed_out_hand_off_requeues_the_requests_in_flight_and_nobody_is_fail
         d.close()
         dv.close()
         gm.close()
+
+
+def test_the_default_dispatcher_is_continuous_for_a_model_alone_on_its_gpu_and_batch_at_a_time_for_two_that_share_one(pkg, tiny):
+    """ptts_dispatch_opts.continuous = 0 is the library's choice (round 5: one continuous engine per GPU wins uniform AND mixed-length traffic; two engines that
+    share a GPU are the batch-at-a-time setting and would lose as continuous engines): which path served a request shows in the statistics, and either way the
+    caller gets its stand-alone audio."""
+    cfg, _, om, gm = tiny
+    c = pkg.RuntimeGenerateConfig(max_steps=5, eos_threshold=float("inf"), want_latents=True)
+    toks = [3, 1, 4, 1, 5]
+    want = gm.generate_batch([toks], [c])[0]
+
+    def serve(models, **kw):
+        d = pkg.Dispatcher(models, max_batch=4, window_us=500, **kw)
+        try:
+            got = d.generate(toks, c)
+            return got, d.stats()
+        finally:
+            d.close()
+
+    got, st = serve([gm])                                   # no `continuous` argument
+    assert st["cont_steps"] > 0, st
+    assert got.n_frames == want.n_frames == 5
+    parity("default dispatcher (continuous) latents", got.latents, want.latents, (1e-4, 5e-3))
+    got, st = serve([gm], continuous=False)
+    assert st["cont_steps"] == 0 and st["batches"] == 1, st
+    parity("dispatcher, continuous off: latents", got.latents, want.latents, (1e-4, 5e-3))
+    g2 = gm.share()
+    try:
+        got, st = serve([gm, g2])                           # two engines on one GPU: the batch collector
+        assert st["cont_steps"] == 0 and st["batches"] == 1, st
+        parity("default dispatcher over two engines of one GPU: latents", got.latents, want.latents, (1e-4, 5e-3))
+    finally:
+        g2.close()

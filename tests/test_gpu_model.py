@@ -502,7 +502,7 @@ def test_dispatcher_coalesces_concurrent_callers_and_returns_each_its_own_audio(
     steps = [int(rng.integers(2, 5)) for _ in range(12)]
     cfg = lambda i: pkg.RuntimeGenerateConfig(max_steps=steps[i], eos_threshold=1e30, want_latents=True)
     want = [gm.generate_batch([prompts[i]], [cfg(i)])[0] for i in range(12)]
-    d = pkg.Dispatcher([gm], max_batch=8, window_us=200_000)
+    d = pkg.Dispatcher([gm], max_batch=8, window_us=200_000, continuous=False)   # the batch collector (one model alone on its GPU defaults to continuous batching)
     got, errs = [None] * 12, [None] * 12
 
     def client(i):

@@ -66,7 +66,7 @@ def _one_process_n_models(pkg, devices):
             got = m.generate_batch(prompts[:8], [c] * 8)
             for a, b in zip(got, want[:8]):
                 assert np.array_equal(a.latents, b.latents) and np.array_equal(a.pcm, b.pcm)
-        d = pkg.Dispatcher(models, max_batch=8, window_us=2000)
+        d = pkg.Dispatcher(models, max_batch=8, window_us=2000, continuous=False)   # (the batch collector: on one GPU per model the default would be continuous batching)
         n_clients = 4 * len(models) * 8
         res, errs = [None] * n_clients, [None] * n_clients
 
