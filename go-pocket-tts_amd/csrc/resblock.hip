@@ -76,18 +76,22 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
     const int r16 = lane & 15, g = lane >> 4;
     const int tiles = (a.t1 - a.t0 + TOUT - 1) / TOUT;
     const int total = a.B * tiles;
-    constexpr int V = TR * C / 4 / NTH;               // float4 of the tile per thread
+    // The tile's rows are fetched in the distribution the MFMA RESULTS have (lane (r16, g) of wave w: tile row 16 w + r16, channels 16 j + 4 g .. + 3): what a lane
+    // fetched is then exactly the residual operand of its stage-C results, and u is read from memory once.  (Round 4 fetched the tile in flat order -- 1-KB
+    // wave-instructions -- and read the residual again behind stage A: "L2-hot" in intent, but the rows had been prefetched a whole tile earlier and half of the
+    // second reads came from HBM: 2.98 GB fetched for a 1.97 GB input, profiles/r4_pmc_mimi.txt.)  A wave-instruction now covers 16 rows x 64 B.
+    constexpr int V = C / 16;                         // float4 of the tile per thread (= TR * C / 4 / NTH)
+    static_assert(V * NTH * 4 == TR * C, "a lane owns one tile row");
     float4 x[V];
+    const int i_own = wave * 16 + r16;                // the tile row this lane fetches, splits, multiplies and stores
     auto request_rows = [&](int t) {                  // rows of tile t (clamped addresses; masked when consumed)
         const int bi_ = t / tiles, row0_ = a.t0 + (t % tiles) * TOUT - HALO;
         const float* ub_ = a.u + (int64_t)bi_ * a.u_bs + (int64_t)a.pad * C;
+        const int gr = row0_ + i_own;
+        const bool ok = gr >= -a.pad && gr < a.L;
+        const float* rp = ub_ + (int64_t)(ok ? gr : 0) * C + 4 * g;
 #pragma unroll
-        for (int j = 0; j < V; j++) {
-            const int e = (tid + j * NTH) * 4, i = e / C, c = e % C;
-            const int gr = row0_ + i;
-            const bool ok = gr >= -a.pad && gr < a.L;
-            x[j] = *reinterpret_cast<const float4*>(ub_ + (int64_t)(ok ? gr : 0) * C + c);
-        }
+        for (int j = 0; j < V; j++) x[j] = *reinterpret_cast<const float4*>(rp + j * 16);
     };
     int tile = blockIdx.x;
     request_rows(tile);
@@ -109,18 +113,16 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
   for (;;) {
     const int bi = tile / tiles, tb = a.t0 + (tile % tiles) * TOUT;   // first output row of the tile
     const int row0 = tb - HALO;                                         // global row of tile row 0
-    const float* ub = a.u + (int64_t)bi * a.u_bs + (int64_t)a.pad * C; // row 0 of the utterance
     PcmRow pr{nullptr, 0, 0};                          // fetched here, where the wait for the tile's rows covers it
     if (FINAL && a.pcm_rows) pr = a.pcm_rows[bi];
 
     // ---- A: u -> elu -> hi/lo planes.  Rows before the utterance (beyond its zero history) or past its end are zeros ----
     {
-#pragma unroll
-        for (int j = 0; j < V; j++) {
-            const int e = (tid + j * NTH) * 4, i = e / C;
-            const int gr = row0 + i;
+        {
+            const int gr = row0 + i_own;
             const bool ok = gr >= -a.pad && gr < a.L;
-            if (!ok) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < V; j++) if (!ok) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (tid < 2 * ROWB / 16) {                    // the two history rows in front of the tile only feed halo rows: zeros
             reinterpret_cast<uint4*>(eu_hi)[tid] = make_uint4(0, 0, 0, 0);
@@ -128,8 +130,8 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
         }
 #pragma unroll
         for (int j = 0; j < V; j++) {
-            const int e = (tid + j * NTH) * 4, i = e / C, c = e % C;
-            const int rho = i + 2;
+            const int c = j * 16 + 4 * g;
+            const int rho = i_own + 2;
             unsigned h01, l01, h23, l23;
             split2r(elu_fast(x[j].x), elu_fast(x[j].y), h01, l01);
             split2r(elu_fast(x[j].z), elu_fast(x[j].w), h23, l23);
@@ -143,14 +145,10 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
     const int i_lane = wave * 16 + r16;               // tile row this lane owns in the MFMA operands / results
     const int gr_lane = row0 + i_lane;
     const bool in_seq = gr_lane >= 0 && gr_lane < a.L;
-    float4 ur[C / 16];                                // residual operand of stage C
-    if constexpr (PERS) {
-        // the residual rows (L2-hot: this block has just read them) are requested BEFORE the next tile's rows, so that stage C's
-        // wait for them leaves the younger HBM requests in flight
+    float4 ur[C / 16];                                // residual operand of stage C: the lane's own share of the tile (rows that are not in_seq are never stored)
 #pragma unroll
-        for (int n = 0; n < C / 16; n++) ur[n] = *reinterpret_cast<const float4*>(ub + (int64_t)(in_seq ? gr_lane : 0) * C + n * 16 + 4 * g);
-        request_rows(min(tile + (int)gridDim.x, total - 1));   // past the block's last tile: a re-read that is never consumed
-    }
+    for (int n = 0; n < C / 16; n++) ur[n] = x[n];
+    if constexpr (PERS) request_rows(min(tile + (int)gridDim.x, total - 1));   // past the block's last tile: a re-read that is never consumed
     // ---- B: hidden = elu(conv_k3(eu) + b1) ----
     {
         constexpr int NT = H / 16, KS = 3 * C / 32;
@@ -201,11 +199,6 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
 #pragma unroll
         for (int n = 0; n < NT; n++) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int gr = gr_lane;
-        // residual operand: requested before the product, consumed after it (L2-hot: this block has just read the rows)
-        if constexpr (!PERS) {
-#pragma unroll
-            for (int n = 0; n < NT; n++) ur[n] = *reinterpret_cast<const float4*>(ub + (int64_t)(in_seq ? gr : 0) * C + n * 16 + 4 * g);
-        }
         const uint4* w2 = (PERS ? wl2 : reinterpret_cast<const uint4*>(a.w2)) + lane;
         const uint4* w2l = reinterpret_cast<const uint4*>(a.w2_lo) + lane;
 #pragma unroll
