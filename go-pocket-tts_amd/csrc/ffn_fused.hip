@@ -81,7 +81,8 @@ constexpr int FF_IMG = FF_W1B + FF_W2B;   // one chunk's images, contiguous in t
 // counters and ordered by hand: every wave waits vmcnt(0) at the one place below where a slot changes hands, in front of the block's barrier.
 // (The compiler's own vmcnt(N) waits stay right: loads return in issue order, so a wait that lets the N youngest VISIBLE loads stay in flight
 // has also seen every older copy land; and no visible load is issued between a copy and that wait.)  m0 carries the LDS address; nothing else
-// in this kernel uses it.
+// in this kernel uses it -- and the compiler keeps nothing in it across statements: m0 is a RESERVED register to LLVM (listing it as a clobber is rejected as
+// "reserved registers on the clobber list"), written right in front of each of the compiler's own uses (s_sendmsg, GWS, v_movrel), none of which these kernels have.
 // One LDS-DMA wave-instruction: lane l's 16 bytes at src_lane -> dst + 16 l.  The wait state between the write of m0 and its use is written out because
 // the compiler's hazard recognizer does not look inside inline assembly (ISA: SALU write of M0 -> LDS "direct" / GDS / sendmsg use needs one).
 __device__ __forceinline__ void ff_dma1k(const char* src_lane, char* dst) {

@@ -66,7 +66,7 @@ __device__ __forceinline__ void tl_split2(float a, float b, unsigned& hi, unsign
 __device__ __forceinline__ int tl_swz(int r) { return ((r >> 2) & 1) | (r & 2) | ((r & 1) << 3); }
 
 // One LDS-DMA wave-instruction: lane l's 16 bytes at src_lane -> lds_base + 16 l (ffn_fused.hip ff_dma1k: inline assembly so that the compiler's wait counters do
-// not serialise the ring; the wait state between the write of m0 and its use is written out)
+// not serialise the ring; the wait state between the write of m0 and its use is written out; m0 is reserved to the compiler, which keeps nothing in it across statements)
 __device__ __forceinline__ void tl_dma1k(const char* src_lane, char* dst) {
     const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)dst;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(base), "v"(src_lane) : "memory");
