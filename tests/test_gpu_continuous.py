@@ -357,3 +357,34 @@ def test_the_default_dispatcher_is_continuous_for_a_model_alone_on_its_gpu_and_b
         parity("default dispatcher over two engines of one GPU: latents", got.latents, want.latents, (1e-4, 5e-3))
     finally:
         g2.close()
+
+
+def test_a_cluster_of_long_utterances_ending_together_is_decoded_in_the_step_chain_and_the_audio_is_the_decoder_on_their_latents(pkg, tiny):
+    """start_decode's second path (round 5): finished utterances with >= 2400 frames between them are decoded on the step stream itself, on the whole chip,
+    instead of beside the following steps on the confined stream.  8 slots x 320 frames end in the same group of steps -> one decode of 2560 frames; a second
+    wave of short requests behind them takes the confined stream again (the two streams hand the decoder's workspace to each other).  Over 320 free-running
+    steps a trajectory is not comparable with a stand-alone run (its prompt is prefilled in a packed launch of other tilings); what is held is what the
+    decode path owns: frame counts, and every request's audio against the decoder run on the request's OWN latents."""
+    cfg, _, om, gm = tiny
+    rng = np.random.default_rng(5)
+    n_long, n_short = 8, 8
+    prompts = [rng.integers(1, cfg.n_bins, size=5).astype(np.int64) for _ in range(n_long + n_short)]
+    steps = [320] * n_long + [int(rng.integers(4, 12)) for _ in range(n_short)]
+    cfgs = [pkg.RuntimeGenerateConfig(max_steps=s, eos_threshold=float("inf"), want_latents=True) for s in steps]
+    d = pkg.Dispatcher([gm], max_batch=8, window_us=20_000, continuous=True, cont_kv_capacity=384, cont_max_steps=320, cont_steps_per_group=4)
+    try:
+        got, errs = run_clients(d, prompts, cfgs)
+        assert not any(errs), errs
+    finally:
+        d.close()
+    for i, g in enumerate(got):
+        assert g.n_frames == steps[i] and g.eos_step == -1, (i, g.n_frames)
+        assert np.isfinite(g.latents).all()
+    for ids in (list(range(n_long)), list(range(n_long, n_long + n_short))):
+        T = max(got[i].n_frames for i in ids)
+        lat = np.zeros((len(ids), T, got[ids[0]].latents.shape[1]), np.float32)
+        for k, i in enumerate(ids):
+            lat[k, : got[i].n_frames] = got[i].latents
+        pcm = gm.decode_latents(lat)
+        for k, i in enumerate(ids):
+            parity(f"serial / confined decode pcm[{i}] vs the decoder on its own latents", got[i].pcm, pcm[k, : got[i].n_frames * 1920], (1e-4, 5e-2))
