@@ -22,6 +22,7 @@
 // The engine has a fixed geometry (slots, KV capacity, step budget); requests that do not fit it or need per-step host work (step /
 // PCM callbacks, lsd_steps > 1) are left to the batch-at-a-time path.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <deque>
 #include <map>
@@ -39,7 +40,10 @@ constexpr int kDecoderShare = 2;      // the decoder's stream gets 1 / kDecoderS
 constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
 constexpr int kDecodeSerialFrames = 2400;   // finished utterances with this many frames between them (a cluster of long, like-length requests ending together) are decoded IN the step chain, on the whole chip: see start_decode
 constexpr int kDecodeMaxAge = 8;      // ... or the oldest has waited this many groups of steps (a caller waiting for audio is a caller not sending its next request)
-constexpr int kBandFrames = 16, kBandPercent = 16;   // a decode pads everything to its longest member: members within max(16 frames, 16 %) of it
+// a decode pads everything to its longest member: members within max(16 frames, 48 %) of it share one.  Round 4 chose 16 % by the padded frame count (64 slots);
+// by TIME the small sub-decodes that rule makes (~370 frames each: 4.6 per decode start at 192 slots) cost more than the padding they save -- the decoder's stream was
+// the engine's bottleneck on mixed traffic.  192 slots, mixed 2-12 s: 16 % 14.5 k x, 33 % 14.9 k, 45 % 15.4 k, 60 % 15.1-15.3 k, 75 % 14.5 k, 100 % 14.3 k.
+constexpr int kBandFrames = 16, kBandPercent = 48;
 
 // the decoder's CU-masked stream of a GPU, shared by the continuous engines on it (created with the first, destroyed with the last)
 std::mutex g_dec_mu;
@@ -123,19 +127,23 @@ struct ContEngine {
     hipEvent_t arena_free[2] = {nullptr, nullptr};
     int arena_turn = 0;
     hipEvent_t ev_steps = nullptr;
-    DevBuf lat[2];                        // the frames of the utterances being decoded, gathered from their staging rows: two decodes' worth, in turn
-    hipEvent_t lat_free[2] = {nullptr, nullptr};
-    bool lat_busy[2] = {false, false};
+    static constexpr int kLat = 4;
+    DevBuf lat[kLat];                     // the frames of the utterances being decoded, gathered from their staging rows: four decodes' worth, in turn
+    hipEvent_t lat_free[kLat] = {nullptr, nullptr, nullptr, nullptr};
+    bool lat_busy[kLat] = {false, false, false, false};
     int lat_turn = 0;
     std::unique_lock<std::mutex> hold;    // the model's mutex, held while the engine has work in flight
     bool use_graph = false;
     int64_t admissions = 0, admitted = 0;
     // (measurement: PTTS_CONT_TRACE=<file> -- one line per group of steps: gap in front of it and its duration on the step stream, what ran beside it)
-    struct GroupRec { hipEvent_t t0, t1; int n_gen, steps, admitted, decodes_started, decoding, joining; };
+    struct GroupRec { hipEvent_t t0, t1; int n_gen, steps, admitted, decodes_started, decoding, joining; float host_turn_us, host_admit_us, host_decode_us, host_wait_us; };
+    std::chrono::steady_clock::time_point tr_last_enqueue = std::chrono::steady_clock::now();
+    double tr_acc_admit_us = 0, tr_acc_decode_us = 0, tr_acc_wait_us = 0;   // host time since the previous group was queued: in cont_admit, in start_decode, waiting for a read-back
     std::vector<GroupRec> trace;
     const char* trace_path = getenv("PTTS_CONT_TRACE");
     int tr_admitted = 0, tr_decodes = 0;
     int64_t tr_frames = 0, tr_padded = 0, tr_subs = 0;   // decoded frames, frames incl. padding to the sub-group's longest, sub-groups
+    double tr_host_gather_us = 0, tr_host_launch_us = 0; int64_t tr_starts = 0;   // host time of start_decode: the gather on the step stream, the decoder's launches
     int64_t steps_run = 0, slot_steps = 0;   // AR steps launched; utterances stepping in them, summed (their ratio: mean occupancy)
 
     explicit ContEngine(Model& model) : m(model) {}
@@ -146,14 +154,16 @@ struct ContEngine {
         if (dec) { (void)hipStreamSynchronize(dec); decoder_stream_release(m.device); }
         if (trace_path && !trace.empty()) {
             if (FILE* f = fopen(trace_path, "a")) {
-                fprintf(f, "# gap_us dur_us n_gen steps admitted decodes_started decoding joining\n");
+                fprintf(f, "# gap_us dur_us n_gen steps admitted decodes_started decoding joining host_us_since_previous_group of_it_in_cont_admit in_start_decode waiting_for_read_backs\n");
                 for (size_t i = 0; i < trace.size(); i++) {
                     float gap = 0.f, dur = 0.f;
                     if (i > 0) (void)hipEventElapsedTime(&gap, trace[i - 1].t1, trace[i].t0);
                     (void)hipEventElapsedTime(&dur, trace[i].t0, trace[i].t1);
-                    fprintf(f, "%.1f %.1f %d %d %d %d %d %d\n", 1e3 * gap, 1e3 * dur, trace[i].n_gen, trace[i].steps, trace[i].admitted, trace[i].decodes_started, trace[i].decoding, trace[i].joining);
+                    fprintf(f, "%.1f %.1f %d %d %d %d %d %d %.0f %.0f %.0f %.0f\n", 1e3 * gap, 1e3 * dur, trace[i].n_gen, trace[i].steps, trace[i].admitted, trace[i].decodes_started, trace[i].decoding, trace[i].joining,
+                            trace[i].host_turn_us, trace[i].host_admit_us, trace[i].host_decode_us, trace[i].host_wait_us);
                 }
                 fprintf(f, "# decoded frames %lld, with padding %lld, in %lld decodes\n", (long long)tr_frames, (long long)tr_padded, (long long)tr_subs);
+                fprintf(f, "# start_decode calls %lld: host time per call %.0f us for the gather + %.0f us for the decoder's launches and copies\n", (long long)tr_starts, tr_host_gather_us / std::max<int64_t>(1, tr_starts), tr_host_launch_us / std::max<int64_t>(1, tr_starts));
                 fclose(f);
             }
             for (auto& g : trace) { (void)hipEventDestroy(g.t0); (void)hipEventDestroy(g.t1); }
@@ -256,6 +266,8 @@ bool cont_accepts(const ContEngine& e, const ptts_request& r) {
 
 // n waiting requests move into free slots (n <= cont_free_slots): voice state, prompt prefill, bookkeeping, noise rows
 void cont_admit(ContEngine& e, const ptts_request* const* reqs, ptts_result* const* results, void* const* tags, int n) {
+    struct Timer { ContEngine& e; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Timer() { e.tr_acc_admit_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); } } admit_timer{e};
     if (n <= 0) return;
     Model& m = e.m;
     e.lock_model();
@@ -417,6 +429,7 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
     for (const ContEngine::Staged& f : fin) fin_frames += f.nf;
     const bool serial = fin_frames >= serial_frames;
     hipStream_t s = m.stream, s2 = serial ? m.stream : e.dec;
+    const auto th0 = std::chrono::steady_clock::now();
     e.tr_decodes += (int)fin.size();
     std::sort(fin.begin(), fin.end(), [](const ContEngine::Staged& x, const ContEngine::Staged& y) { return x.nf > y.nf; });   // like lengths together: less padding
     // sub-groups whose decode fits the workspace; their frames are gathered FIRST, all of them, and on the AR stream itself: the staging rows are that
@@ -443,24 +456,29 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
         for (size_t i = at; i < end; i++) e.tr_frames += fin[i].nf;
         at = end;
     }
-    const int lt = e.lat_turn;
-    e.lat_turn ^= 1;
+    // (four buffers in rotation: with two, the step stream waited here for the decode BEFORE LAST to end whenever the decoder's stream had a backlog -- which
+    // on mixed traffic it has most of the time: 2.5 ms in front of every group that followed a decode start, PTTS_CONT_TRACE)
+    const int lt = e.lat_turn, lprev = (lt + ContEngine::kLat - 1) % ContEngine::kLat;
+    e.lat_turn = (lt + 1) % ContEngine::kLat;
     DevBuf& lat_all = e.lat[lt];
-    if (e.lat_busy[lt]) PTTS_HIP(hipStreamWaitEvent(s, e.lat_free[lt], 0));   // the decode before last has read this buffer (long done)
+    if (e.lat_busy[lt]) PTTS_HIP(hipStreamWaitEvent(s, e.lat_free[lt], 0));   // the decode four starts ago has read this buffer
     lat_all.ensure(total * sizeof(float));
-    PTTS_HIP(hipMemsetAsync(lat_all.p, 0, total * sizeof(float), s));
-    for (const Sub& sb : subs)
-        for (size_t i = sb.at; i < sb.end; i++) {
-            const ContEngine::Staged& f = fin[i];
-            if (f.nf > 0)
-                PTTS_HIP(hipMemcpyAsync(lat_all.as<float>() + sb.off + (i - sb.at) * (size_t)sb.T * ld, e.stage.as<float>() + (size_t)f.row * b.max_steps * ld,
-                                        (size_t)f.nf * ld * sizeof(float), hipMemcpyDeviceToDevice, s));
-        }
+    {   // one gather launch per 128 utterances (its table rides in the kernel arguments) instead of a memset and a copy per utterance
+        GatherTable tab;
+        int nt = 0;
+        for (const Sub& sb : subs)
+            for (size_t i = sb.at; i < sb.end; i++) {
+                tab.rows[nt++] = GatherTable::Row{(int32_t)fin[i].row, (int32_t)(sb.off + (i - sb.at) * (size_t)sb.T * ld), (int32_t)std::max(0, fin[i].nf), (int32_t)sb.T};
+                if (nt == 128) { launch_gather_frames(tab, nt, e.stage.as<float>(), (int64_t)b.max_steps * ld, lat_all.as<float>(), ld, s); nt = 0; }
+            }
+        launch_gather_frames(tab, nt, e.stage.as<float>(), (int64_t)b.max_steps * ld, lat_all.as<float>(), ld, s);
+    }
+    const auto th1 = std::chrono::steady_clock::now();
     if (s2 != s) {
         PTTS_HIP(hipEventRecord(e.ev_steps, s));
         PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
     }
-    if (e.lat_busy[lt ^ 1]) PTTS_HIP(hipStreamWaitEvent(s2, e.lat_free[lt ^ 1], 0));   // the previous decode -- possibly on the other stream -- has left the decoder's workspace
+    if (e.lat_busy[lprev]) PTTS_HIP(hipStreamWaitEvent(s2, e.lat_free[lprev], 0));   // the previous decode -- possibly on the other stream -- has left the decoder's workspace
     for (const Sub& sb : subs) {
         const size_t at = sb.at, end = sb.end;
         const int T = sb.T;
@@ -511,6 +529,10 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
     }
     PTTS_HIP(hipEventRecord(e.lat_free[lt], s2));
     e.lat_busy[lt] = true;
+    e.tr_starts++;
+    e.tr_host_gather_us += std::chrono::duration<double, std::micro>(th1 - th0).count();
+    e.tr_host_launch_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th1).count();
+    e.tr_acc_decode_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - th0).count();
     fin.clear();
 }
 
@@ -520,13 +542,25 @@ static void take_snapshot(ContEngine& e, ContEngine::Snap& sn, std::vector<void*
     Model& m = e.m;
     Batch& b = *e.b;
     const int B = e.B;
-    PTTS_HIP(hipEventSynchronize(sn.ready));
+    {
+        const auto tw = std::chrono::steady_clock::now();
+        PTTS_HIP(hipEventSynchronize(sn.ready));
+        e.tr_acc_wait_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count();
+    }
     sn.pending = false;
     if (sn.host[5 * (size_t)B]) { sn.host[5 * (size_t)B] = 0; flow_cluster_fault(b); }   // throws: the dispatcher fails everyone in flight and rebuilds the engine
     const int32_t* active = sn.host;
     const int32_t* n_frames = sn.host + 3 * (size_t)B;
     const int32_t* eos_step = sn.host + 4 * (size_t)B;
     std::vector<int32_t> retire;
+    // the frames of the utterances that ended move to their staging rows in ONE launch (a copy per utterance held the step stream for ~100 us each)
+    const int ld = m.d.ldim;
+    GatherTable moves;
+    int n_moves = 0;
+    auto flush_moves = [&] {
+        launch_gather_frames(moves, n_moves, b.latents.as<float>(), (int64_t)b.max_steps * ld, e.stage.as<float>(), ld, m.stream);
+        n_moves = 0;
+    };
     for (int sl = 0; sl < B; sl++) {
         ContEngine::Slot& so = e.slots[(size_t)sl];
         if (!so.busy || so.joining || sn.seq <= so.admit_seq) continue;   // (a read-back from before the slot was filled says nothing about it)
@@ -538,18 +572,20 @@ static void take_snapshot(ContEngine& e, ContEngine::Snap& sn, std::vector<void*
             so = ContEngine::Slot{};
             e.n_gen--;
         } else if (!active[sl]) {   // ended: its frames move to a staging row (queued behind the group in flight), the slot is free
-            const int nf = n_frames[sl], ld = m.d.ldim;
-            if (e.stage_free.empty()) { start_decode(e, e.staged); }   // (cannot run dry before this: 2 B rows, at most B slots + what one turn adds)
+            const int nf = n_frames[sl];
+            if (e.stage_free.empty()) { flush_moves(); start_decode(e, e.staged); }   // (cannot run dry before this: 2 B rows, at most B slots + what one turn adds)
             const int row = e.stage_free.back();
             e.stage_free.pop_back();
-            if (nf > 0)
-                PTTS_HIP(hipMemcpyAsync(e.stage.as<float>() + (size_t)row * b.max_steps * ld, b.latents.as<float>() + (size_t)sl * b.max_steps * ld, (size_t)nf * ld * sizeof(float),
-                                        hipMemcpyDeviceToDevice, m.stream));
+            if (nf > 0) {
+                moves.rows[n_moves++] = GatherTable::Row{(int32_t)sl, (int32_t)((int64_t)row * b.max_steps * ld), (int32_t)nf, (int32_t)nf};
+                if (n_moves == 128) flush_moves();
+            }
             e.staged.push_back(ContEngine::Staged{so.req, so.res, so.tag, nf, eos_step[sl], row, e.seq});
             so = ContEngine::Slot{};
             e.n_gen--;
         }
     }
+    flush_moves();
     if (!retire.empty()) {   // queued behind the group in flight; whatever refills the slot is queued behind this
         const int turn = e.arena_turn;
         e.arena_turn ^= 1;
@@ -587,6 +623,10 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
             if (e.trace_path) {
                 PTTS_HIP(hipEventCreate(&rec.t0)); PTTS_HIP(hipEventCreate(&rec.t1));
                 rec.n_gen = e.n_gen; rec.steps = steps; rec.admitted = e.tr_admitted; rec.decodes_started = e.tr_decodes; rec.decoding = (int)e.decoding.size(); rec.joining = (int)e.joining.size();
+                const auto tn = std::chrono::steady_clock::now();
+                rec.host_turn_us = (float)std::chrono::duration<double, std::micro>(tn - e.tr_last_enqueue).count();
+                rec.host_admit_us = (float)e.tr_acc_admit_us; rec.host_decode_us = (float)e.tr_acc_decode_us; rec.host_wait_us = (float)e.tr_acc_wait_us;
+                e.tr_last_enqueue = tn; e.tr_acc_admit_us = e.tr_acc_decode_us = e.tr_acc_wait_us = 0;
                 e.tr_admitted = e.tr_decodes = 0;
                 PTTS_HIP(hipEventRecord(rec.t0, s));
             }
@@ -597,23 +637,29 @@ void cont_advance(ContEngine& e, int steps, std::vector<void*>& done, bool drain
             e.steps_run += steps; e.slot_steps += (int64_t)steps * e.n_gen;
             ContEngine::Snap& sn = e.snaps[e.seq & 1];
             if (sn.pending) take_snapshot(e, sn, done);   // (cannot happen: the older read-back is consumed every turn)
-            PTTS_HIP(hipMemcpyAsync(sn.host, b.st.active, (size_t)5 * B * sizeof(int32_t), hipMemcpyDeviceToHost, s));
-            if (b.fc_ok) PTTS_HIP(hipMemcpyAsync(sn.host + 5 * (size_t)B, b.fc_fault(), sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            launch_readback_i32(b.st.active, 5 * B, b.fc_ok ? reinterpret_cast<const int32_t*>(b.fc_fault()) : nullptr, 1, sn.host, s);   // (a kernel, not the copy engine: kernels.hip)
             PTTS_HIP(hipEventRecord(sn.ready, s));
             sn.seq = e.seq; sn.pending = true;
         }
-        // the older read-back first; the newest as well when nothing else will be queued behind it
-        ContEngine::Snap& older = e.snaps[(e.seq + 1) & 1];
-        if (older.pending) take_snapshot(e, older, done);
-        ContEngine::Snap& newest = e.snaps[e.seq & 1];
-        if (newest.pending && (drain || e.n_gen == 0)) take_snapshot(e, newest, done);
         // decode: a good handful at a time (small decodes are inefficient and disturb the step chain as much as large ones), or whatever
         // there is once the oldest has waited eight groups / nothing generates / the caller drains
-        if (!e.staged.empty()) {
+        auto decode_if_due = [&] {
+            if (e.staged.empty()) return;
             uint64_t oldest = e.seq;
             for (const ContEngine::Staged& f : e.staged) oldest = std::min(oldest, f.seq);
             if ((int)e.staged.size() >= std::min(kDecodeMin, std::max(4, B / 3)) || (int)(e.seq - oldest) >= kDecodeMaxAge || e.n_gen == 0 || drain) start_decode(e, e.staged);
-        }
+        };
+        // While steps are running the host is about to WAIT for the older read-back (the group before the one just queued is still on the GPU: ~1.3 ms at 192 slots):
+        // the decoder's ~50-200 launches (0.8 ms of host time per start) go in front of that wait, for what earlier turns staged -- behind it they sat on the critical
+        // path of the next group's enqueue, and the step stream stood still for ~1.3 ms in front of every group that followed a decode start (PTTS_CONT_TRACE)
+        ContEngine::Snap& older = e.snaps[(e.seq + 1) & 1];
+        const bool overlap = older.pending && e.n_gen > 0 && !drain;
+        if (overlap) decode_if_due();
+        // the older read-back first; the newest as well when nothing else will be queued behind it
+        if (older.pending) take_snapshot(e, older, done);
+        ContEngine::Snap& newest = e.snaps[e.seq & 1];
+        if (newest.pending && (drain || e.n_gen == 0)) take_snapshot(e, newest, done);
+        if (!overlap || e.n_gen == 0) decode_if_due();
         while (!e.decoding.empty()) {
             ContEngine::Pending& p = e.decoding.front();
             if (drain || (e.n_gen == 0 && e.n_finished() == 0)) PTTS_HIP(hipEventSynchronize(p.done));

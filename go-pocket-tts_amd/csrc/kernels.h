@@ -366,6 +366,9 @@ void launch_step_finish(const StepState& s, const float* frame, const float* eos
 struct NoiseSpec { uint64_t seed; float sigma; int32_t rows; };
 void launch_noise_fill(const NoiseSpec* spec_dev, int n_slots, int max_rows, float* out, int64_t out_stride, int ldim, hipStream_t stream);
 // continuous batching: (re)initialise the bookkeeping of the slots a new utterance moves into; switch cancelled slots off
+struct GatherTable { struct Row { int32_t src_row, dst_off, nf, T; }; Row rows[128]; };   // (2 KB of kernel arguments)
+void launch_gather_frames(const GatherTable& t, int n, const float* stage, int64_t row_stride, float* dst, int ld, hipStream_t stream);   // ld % 4 == 0
+void launch_readback_i32(const int32_t* a, int na, const int32_t* b, int nb, int32_t* host, hipStream_t stream);   // host: page-locked, device-visible; [a | b]
 struct SlotAdmit { int32_t slot, max_steps, frames_after_eos; float eos_threshold; int32_t kv_len, pre_len; const void* pre_k; const void* pre_v; };
 void launch_slot_admit(const StepState& s, int32_t* pre_len, const void** pre_k, const void** pre_v, const SlotAdmit* dev, int n, hipStream_t stream);
 void launch_slot_retire(const StepState& s, const int32_t* slots_dev, int n, hipStream_t stream);

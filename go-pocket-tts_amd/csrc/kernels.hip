@@ -251,6 +251,35 @@ void launch_avg2(const float* a, const float* b, float* y, int n, hipStream_t st
     hipLaunchKernelGGL(k_avg2, dim3((n + 255) / 256), dim3(256), 0, stream, a, b, y, n);
 }
 
+// The continuous engine's decode input: the frames of up to 128 finished utterances from their staging rows into one packed [utterance][T][ld] block, the padding
+// behind an utterance's last frame zeroed -- one launch with its table in the kernel arguments (as a memset + one hipMemcpyAsync per utterance the step stream
+// stood still for ~2.5 ms per decode: 25 copy-engine round trips of ~100 us each, profiles/r5_serve_sweep.txt "group traces").
+__global__ __launch_bounds__(256) void k_gather_frames(GatherTable t, const float* stage, int64_t row_stride, float* dst, int ld) {
+    const GatherTable::Row r = t.rows[blockIdx.x];
+    const float4* src = reinterpret_cast<const float4*>(stage + (int64_t)r.src_row * row_stride);
+    float4* out = reinterpret_cast<float4*>(dst + r.dst_off);
+    const int n_copy = r.nf * ld / 4, n_all = r.T * ld / 4;
+    for (int i = threadIdx.x; i < n_all; i += 256) out[i] = i < n_copy ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+void launch_gather_frames(const GatherTable& t, int n, const float* stage, int64_t row_stride, float* dst, int ld, hipStream_t stream) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_gather_frames, dim3((unsigned)n), dim3(256), 0, stream, t, stage, row_stride, dst, ld);
+}
+
+// The continuous engine's read-back of the slots' counters: a kernel that stores them straight into page-locked host memory, in order on the step stream.  (As
+// hipMemcpyAsync the read-back went through the copy engine, behind whatever PCM the decoder's stream had queued there: the step stream stood still for up to
+// 2.5 ms in front of every group that followed a decode start, PTTS_CONT_TRACE.)
+__global__ void k_readback_i32(const int32_t* a, int na, const int32_t* b, int nb, int32_t* host) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < na) host[i] = a[i];
+    else if (i < na + nb) host[i] = b[i - na];
+}
+void launch_readback_i32(const int32_t* a, int na, const int32_t* b, int nb, int32_t* host, hipStream_t stream) {
+    const int n = na + (b ? nb : 0);
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_readback_i32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a, na, b, b ? nb : 0, host);
+}
+
 __global__ void k_fill_i32(int32_t* p, int32_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
