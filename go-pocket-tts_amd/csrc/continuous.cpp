@@ -132,6 +132,9 @@ struct ContEngine {
     hipEvent_t lat_free[kLat] = {nullptr, nullptr, nullptr, nullptr};
     bool lat_busy[kLat] = {false, false, false, false};
     int lat_turn = 0;
+    // where the decoder's last kernel stores each utterance's samples: page-locked result rows (PcmRow table: kLat x 2 B entries, host side page-locked, uploaded per sub-decode)
+    PcmRow* rows_host = nullptr;
+    DevBuf rows_dev;
     std::unique_lock<std::mutex> hold;    // the model's mutex, held while the engine has work in flight
     bool use_graph = false;
     int64_t admissions = 0, admitted = 0;
@@ -173,6 +176,7 @@ struct ContEngine {
         for (hipEvent_t e : free_events) (void)hipEventDestroy(e);
         if (ev_steps) (void)hipEventDestroy(ev_steps);
         for (hipEvent_t ev : lat_free) if (ev) (void)hipEventDestroy(ev);
+        if (rows_host) (void)hipHostFree(rows_host);
         for (Snap& sn : snaps) { if (sn.host) (void)hipHostFree(sn.host); if (sn.ready) (void)hipEventDestroy(sn.ready); }
         for (int i = 0; i < 2; i++) { if (arenas[i].base) (void)hipHostFree(arenas[i].base); if (arena_free[i]) (void)hipEventDestroy(arena_free[i]); }
         b.reset();
@@ -237,6 +241,8 @@ ContEngine* cont_create(Model& m, int slots, int kv_cap, int max_steps) {
     PTTS_HIP(hipEventCreateWithFlags(&e->ev_steps, hipEventDisableTiming));
     for (hipEvent_t& ev : e->lat_free) PTTS_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     for (DevBuf& l : e->lat) l.ensure((size_t)2 * slots * (size_t)max_steps * m.d.ldim * sizeof(float));   // every staging row at full length
+    PTTS_HIP(hipHostMalloc((void**)&e->rows_host, sizeof(PcmRow) * ContEngine::kLat * 2 * (size_t)slots, hipHostMallocDefault));
+    e->rows_dev.ensure(sizeof(PcmRow) * ContEngine::kLat * 2 * (size_t)slots);
     m.tcomb_for(1);
     // the decoder's workspaces at their largest, so that a later, bigger group of finished utterances never reallocates a buffer an
     // earlier group's kernels are still using
@@ -461,7 +467,10 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
     const int lt = e.lat_turn, lprev = (lt + ContEngine::kLat - 1) % ContEngine::kLat;
     e.lat_turn = (lt + 1) % ContEngine::kLat;
     DevBuf& lat_all = e.lat[lt];
-    if (e.lat_busy[lt]) PTTS_HIP(hipStreamWaitEvent(s, e.lat_free[lt], 0));   // the decode four starts ago has read this buffer
+    if (e.lat_busy[lt]) {   // the decode four starts ago has read this buffer -- and the host rewrites that decode's row table below: it has been uploaded
+        PTTS_HIP(hipStreamWaitEvent(s, e.lat_free[lt], 0));
+        PTTS_HIP(hipEventSynchronize(e.lat_free[lt]));
+    }
     lat_all.ensure(total * sizeof(float));
     {   // one gather launch per 128 utterances (its table rides in the kernel arguments) instead of a memset and a copy per utterance
         GatherTable tab;
@@ -479,6 +488,7 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
         PTTS_HIP(hipStreamWaitEvent(s2, e.ev_steps, 0));
     }
     if (e.lat_busy[lprev]) PTTS_HIP(hipStreamWaitEvent(s2, e.lat_free[lprev], 0));   // the previous decode -- possibly on the other stream -- has left the decoder's workspace
+    size_t n_rows_used = 0;
     for (const Sub& sb : subs) {
         const size_t at = sb.at, end = sb.end;
         const int T = sb.T;
@@ -488,11 +498,36 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
         mimi_setup(m, mw, nb, T);
         mimi_zero_history(m, mw, s2);
         DevBuf& pcm = m.work(7, (size_t)nb * T * spf * sizeof(float));
-        mimi_range(m, mw, lat, (int64_t)T * ld, 0, T, pcm.as<float>(), nullptr, s2);
+        // The result rows first: the decoder's last kernel stores every utterance's samples (f32 or int16) straight into its page-locked result buffer -- the kernel's
+        // stores ARE the device -> host transfer, as in the one-shot path (runtime.cpp generate_chunk): no PCM copy per utterance on the decoder's stream, no
+        // conversion launch.  (A pool that had to fall back to pageable memory, or a decoder shape the fused last stage does not take: the buffer + copy path below.)
+        const size_t row0 = (size_t)lt * 2 * (size_t)e.B + n_rows_used;
+        PcmRow* hrows = e.rows_host + row0;
+        bool direct = row0 + (size_t)nb <= (size_t)ContEngine::kLat * 2 * (size_t)e.B && n_rows_used + (size_t)nb <= 2 * (size_t)e.B;
+        for (int i = 0; i < nb; i++) {
+            const ContEngine::Staged& f = fin[at + (size_t)i];
+            ptts_result& r = *f.res;
+            r.n_frames = f.nf; r.eos_step = f.eos; r.n_samples = (int64_t)f.nf * spf; r.status = PTTS_OK;
+            const bool s16r = f.req->pcm_format == PTTS_PCM_S16;
+            void* dst = result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * (s16r ? sizeof(int16_t) : sizeof(float)));
+            if (s16r) r.pcm16 = (int16_t*)dst; else r.pcm = (float*)dst;
+            if (!dst) { r.status = PTTS_ENOMEM; direct = false; continue; }
+            direct = direct && result_is_pinned(dst);
+            if (direct) hrows[i] = PcmRow{dst, (int32_t)std::min<int64_t>(r.n_samples, INT32_MAX), s16r ? 1 : 0};
+        }
+        const PcmRow* drows = nullptr;
+        if (direct) {
+            PcmRow* dr = e.rows_dev.as<PcmRow>() + row0;
+            PTTS_HIP(hipMemcpyAsync(dr, hrows, (size_t)nb * sizeof(PcmRow), hipMemcpyHostToDevice, s2));   // (page-locked source, rewritten no sooner than kLat decode starts later)
+            drows = dr;
+            n_rows_used += (size_t)nb;
+        }
+        bool stored = false;
+        mimi_range(m, mw, lat, (int64_t)T * ld, 0, T, pcm.as<float>(), nullptr, s2, drows, &stored);
         bool any_s16 = false;
         for (int i = 0; i < nb; i++) any_s16 |= fin[at + (size_t)i].req->pcm_format == PTTS_PCM_S16;
         DevBuf* s16 = nullptr;
-        if (any_s16) {
+        if (!stored && any_s16) {
             s16 = &m.work(8, (size_t)nb * T * spf * sizeof(int16_t));
             launch_pcm16(pcm.as<float>(), s16->as<int16_t>(), (int64_t)nb * T * spf, s2);
         }
@@ -501,16 +536,10 @@ static void start_decode(ContEngine& e, std::vector<ContEngine::Staged>& fin) {
             const ContEngine::Staged& f = fin[at + (size_t)i];
             ptts_result& r = *f.res;
             const int nf = f.nf;
-            r.n_frames = nf; r.eos_step = f.eos; r.n_samples = (int64_t)nf * spf; r.status = PTTS_OK;
-            if (f.req->pcm_format == PTTS_PCM_S16) {
-                r.pcm16 = (int16_t*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(int16_t));
-                if (!r.pcm16) r.status = PTTS_ENOMEM;
-                else if (r.n_samples > 0)
+            if (!stored && r.status == PTTS_OK && r.n_samples > 0) {
+                if (f.req->pcm_format == PTTS_PCM_S16)
                     PTTS_HIP(hipMemcpyAsync(r.pcm16, s16->as<int16_t>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(int16_t), hipMemcpyDeviceToHost, s2));
-            } else {
-                r.pcm = (float*)result_alloc((size_t)std::max<int64_t>(1, r.n_samples) * sizeof(float));
-                if (!r.pcm) r.status = PTTS_ENOMEM;
-                else if (r.n_samples > 0)
+                else
                     PTTS_HIP(hipMemcpyAsync(r.pcm, pcm.as<float>() + (size_t)i * T * spf, (size_t)r.n_samples * sizeof(float), hipMemcpyDeviceToHost, s2));
             }
             if (f.req->want_latents && r.status == PTTS_OK) {
