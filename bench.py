@@ -253,7 +253,7 @@ def two_barrier_pass(barrier, sync, prepare, timed):
     return dt, err
 
 
-def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_client=2):
+def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_client=4):
     """BASELINE.json configs[3] names the serve-mode worker pool (internal/server/server.go:119-143,398-421): this rank's share of it is one
     dispatcher over two engines of its GPU (one weight arena), fed by closed-loop clients that each synthesise 10-s utterances back to back
     (64 per engine in flight).  Returns (audio seconds, wall seconds, p50 latency) of the timed rounds; an untimed round comes first."""
@@ -780,7 +780,7 @@ def main():
             serve["two_engines_batch_at_a_time"] = {
                 "value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
                 "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
-                "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 2 "
+                "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 4 "
                           f"requests of {wl['frames']} frames, PCM16 (rounds 2-4's serve_mode figure); {world} GPU(s)"}
         if "uniform" in serve:   # serve_mode = uniform traffic through the default configuration; the other legs beside it
             result["serve_mode"] = dict(serve.pop("uniform"), **serve)
