@@ -752,6 +752,21 @@ def main():
         def everywhere(ok: bool) -> bool:
             return max_over_ranks(0.0 if ok else 1.0, world, dev) == 0.0
         serve = {}
+        # (the two-engine batch-at-a-time leg first, as in rounds 2-4: run behind the continuous legs it came out bimodal, 10-11 k or 15.7-16 k x from run to run --
+        # which hardware queues its engines' streams land on depends on what was created and destroyed before them: DESIGN.md section 5, the stream / queue rule)
+        try:
+            sp = serve_pass(pkg, model, wl, prompts, voice, barrier, sync)
+        except Exception as e:  # noqa: BLE001
+            log(f"[bench] two-engine serve pass failed on rank {rank}: {e}")
+            sp = None
+        if everywhere(sp is not None):
+            a_s, dt_s, p50_s, mb_s = sp
+            dt_all = max_over_ranks(dt_s, world, dev)
+            serve["two_engines_batch_at_a_time"] = {
+                "value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
+                "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
+                "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 4 "
+                          f"requests of {wl['frames']} frames, PCM16 (rounds 2-4's serve_mode figure); {world} GPU(s)"}
         for key, kw, what in (("uniform", dict(slots=256, clients=512, per_client=4, mixed=False), f"512 closed-loop clients x 4 requests of {wl['frames']} frames"),
                               ("mixed_continuous", dict(slots=192, clients=384, per_client=4, mixed=True),
                                "384 closed-loop clients x 4 requests of 25..150 frames (2-12 s, uniformly drawn)")):
@@ -769,19 +784,6 @@ def main():
                     "per_rank_xrt": [round(x / dt_all, 1) for x in gather_over_ranks(a_m, world, dev)], "mean_occupied_slots": round(occ_m, 1), "flow_cluster_fallbacks": fb_m,
                     "config": f"per GPU: the dispatcher's default for one model on its GPU -- one continuous-batching engine, {kw['slots']} slots; {what}, PCM16; "
                               f"{world} GPU(s), no exchange between them"}
-        try:
-            sp = serve_pass(pkg, model, wl, prompts, voice, barrier, sync)
-        except Exception as e:  # noqa: BLE001
-            log(f"[bench] two-engine serve pass failed on rank {rank}: {e}")
-            sp = None
-        if everywhere(sp is not None):
-            a_s, dt_s, p50_s, mb_s = sp
-            dt_all = max_over_ranks(dt_s, world, dev)
-            serve["two_engines_batch_at_a_time"] = {
-                "value": round(a_s * world / dt_all, 1), "unit": "x real-time", "p50_utterance_latency_ms": round(1e3 * p50_s, 1),
-                "per_rank_xrt": [round(a_s / e, 1) for e in gather_over_ranks(dt_s, world, dev)], "mean_batch": round(mb_s, 1),
-                "config": f"per GPU: one dispatcher (batch-at-a-time collector, window 3 ms) over 2 engines sharing the weight arena, 128 closed-loop clients x 4 "
-                          f"requests of {wl['frames']} frames, PCM16 (rounds 2-4's serve_mode figure); {world} GPU(s)"}
         if "uniform" in serve:   # serve_mode = uniform traffic through the default configuration; the other legs beside it
             result["serve_mode"] = dict(serve.pop("uniform"), **serve)
         elif serve:
