@@ -798,7 +798,7 @@ def main():
         # more rows per AR step through one engine (a step's time hardly depends on its rows): labelled extras beside the unchanged 64-per-GPU headline
         for bw in (128, 256):
             try:
-                result[f"b{bw}"] = wide_batch_pass(pkg, model, wl, bw, voice, max(3, args.steps // 2), sync)
+                result[f"b{bw}"] = wide_batch_pass(pkg, model, wl, bw, voice, max(3, args.steps), sync)
             except Exception as e:  # noqa: BLE001
                 log(f"[bench] b{bw} pass failed: {e}")
     if rank == 0 and world == 1 and not args.no_b1 and not args.no_two_engines and args.workload == "b64_10s_bf16":
