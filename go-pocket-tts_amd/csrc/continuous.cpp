@@ -36,6 +36,9 @@ namespace {
 // The pacing below was swept on one MI355X at 128 clients, utterances of 2-12 s (profiles/r4_serve_sweep.txt; tools/gpu_cont_trace.sh), and again in round 5 at
 // 128-256 slots (profiles/r5_serve_sweep.txt: decodes of 16 / 32 / 48 utterances alike; 85 / 96 CUs for the decoder -12..-30 %, 160 / 256 CUs -3..-5 %;
 // every decode in the step chain with 32 / 48 / 64 / 96 utterances per decode: 13.5 / 14.1 / 14.2 k x at 192 slots against 14.3 k, 14.9 / 15.2 k at 256 against 14.4 k):
+// (the decoder's CUs once more on the final engine of round 5, mixed traffic: 192 slots 96 / 128 / 160 / 176 / 192 / 208 / 224 / 256 CUs = 13.0 / 15.7 / 16.0 / 16.0 / 16.5 / 16.3 /
+// 15.6 / 15.4 k x; 256 slots 128 / 160 / 192 / 224 = 15.5 / 16.4 / 16.3 / 16.7 k -- but 192 CUs cost uniform traffic 5 % (19.4 k against 20.5 k) and smaller engines 5-10 %
+// (128 slots 13.3 k against 14.8 k, 64 slots 10.4 k against 11.0 k): half of the CUs stays)
 constexpr int kDecoderShare = 2;      // the decoder's stream gets 1 / kDecoderShare of the device's CUs (128 of the MI355X's 256): see cont_create
 constexpr int kDecodeMin = 16;        // finished utterances worth a decode ...
 constexpr int kDecodeSerialFrames = 2400;   // finished utterances with this many frames between them (a cluster of long, like-length requests ending together) are decoded IN the step chain, on the whole chip: see start_decode
