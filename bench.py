@@ -367,15 +367,23 @@ def run_workload(pkg, model, wl, prompts, voice, steps, warmup, barrier, sync, *
     out = None
     for _ in range(warmup):
         out = model.generate_batch(toks, cfgs)   # held like in the timed loop: the pinned result pool reaches its steady state (two sets)
-    sync(); barrier()
-    lat = []
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        s0 = time.perf_counter()
-        out = model.generate_batch(toks, cfgs)
-        lat.append(time.perf_counter() - s0)
-    sync(); barrier()
-    elapsed = time.perf_counter() - t0
+    # (the interpreter's cyclic collector stays out of the timed region: a full collection of this process -- torch and numpy imported -- is a 40-50 ms pause, and it
+    # came at the same step of every 128-utterance run; nothing the loop allocates is cyclic)
+    import gc
+    gc.collect()
+    gc.disable()
+    try:
+        sync(); barrier()
+        lat = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            s0 = time.perf_counter()
+            out = model.generate_batch(toks, cfgs)
+            lat.append(time.perf_counter() - s0)
+        sync(); barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     log("[bench] per-step ms: " + " ".join(f"{1e3*x:.1f}" for x in lat))
     frames = sum(o.n_frames for o in out)
     assert all(o.n_frames == wl["frames"] and o.pcm.shape[0] == wl["frames"] * 1920 for o in out)
