@@ -232,6 +232,31 @@ def gen_cfgs(pkg, wl, n, voice, **kw):
     return [pkg.RuntimeGenerateConfig(**base) for _ in range(n)]
 
 
+def run_client_threads(client, clients, n):
+    """clients closed-loop client threads, each client(i, n); every thread that started is joined whatever happens (a rank that cannot start them all -- a
+    task limit on a node that carries eight ranks -- reports the failure instead of leaving requests in flight behind its back)."""
+    import threading
+    failures, started = [], []
+
+    def guarded(i):
+        try:
+            client(i, n)
+        except Exception as e:  # noqa: BLE001
+            failures.append(e)
+
+    try:
+        for i in range(clients):
+            t = threading.Thread(target=guarded, args=(i,))
+            t.start()
+            started.append(t)
+    except RuntimeError as e:      # "can't start new thread"
+        failures.append(e)
+    for t in started:
+        t.join()
+    if failures:
+        raise failures[0]
+
+
 def two_barrier_pass(barrier, sync, prepare, timed):
     """prepare() builds and warms (untimed), timed() is the measured round; returns (wall seconds of timed(), the exception or None).  EVERY rank reaches both
     barriers whatever happens on it -- a rank whose engine failed must not leave the others waiting inside a collective."""
@@ -273,9 +298,7 @@ def serve_pass(pkg, model, wl, prompts, voice, barrier, sync, clients=128, per_c
             assert r.n_frames == wl["frames"]
 
     def round_(n):
-        ts = [threading.Thread(target=client, args=(i, n)) for i in range(clients)]
-        [t.start() for t in ts]
-        [t.join() for t in ts]
+        run_client_threads(client, clients, n)
 
     def prepare():
         st["m2"] = m2 = model.share()
@@ -332,9 +355,7 @@ def serve_continuous_pass(pkg, model, wl, voice, barrier, sync, slots=192, clien
                 done.append(nf)
 
     def round_(n):
-        ts = [threading.Thread(target=client, args=(i, n)) for i in range(clients)]
-        [t.start() for t in ts]
-        [t.join() for t in ts]
+        run_client_threads(client, clients, n)
 
     def prepare():
         st["eng"] = eng = model.share()

@@ -121,3 +121,27 @@ def test_a_serve_pass_that_fails_on_one_rank_still_reaches_both_barriers():
         assert (err is None) == (fail_in is None)
         assert ("timed" in calls) == (fail_in != "prepare")        # nothing is timed on a rank whose preparation failed
         assert calls[-1] == "barrier"
+
+
+def test_client_threads_are_all_joined_and_a_failure_in_one_is_reported():
+    """bench.run_client_threads: the closed-loop clients of the serve legs; a client that fails (or a thread that cannot be started) fails the leg on that rank
+    only after every started thread has ended -- nothing keeps calling into a dispatcher that is about to be closed."""
+    sys.path.insert(0, ROOT)
+    import bench
+    import threading
+    import time
+    seen, lock = [], threading.Lock()
+
+    def client(i, n):
+        time.sleep(0.01 * (i % 3))
+        with lock:
+            seen.append((i, n))
+        if i == 5:
+            raise ValueError("client 5 failed")
+
+    with pytest.raises(ValueError, match="client 5"):
+        bench.run_client_threads(client, 12, 2)
+    assert sorted(seen) == [(i, 2) for i in range(12)]          # everybody ran to the end before the failure was reported
+    seen.clear()
+    bench.run_client_threads(lambda i, n: seen.append(i), 4, 1)
+    assert sorted(seen) == [0, 1, 2, 3]
