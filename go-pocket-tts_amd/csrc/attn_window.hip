@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[i].v, qh[i].v, s, 0, 0, 0);
-            if constexpr (!KVBF16) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[i].v, qh[i].v, s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[i].v, ql[i].v, s, 0, 0, 0);
+            if constexpr (!KVBF16) PTTS_LO_MFMA(s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kl[i].v, qh[i].v, s, 0, 0, 0));
+            PTTS_LO_MFMA(s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kh[i].v, ql[i].v, s, 0, 0, 0));
         }
         float tmax = -INFINITY;
 #pragma unroll
@@ -169,11 +169,11 @@ __global__ __launch_bounds__(256) void k_attn_window(AttnArgs a, int qtiles) {
                 split2w(v1[8 * i + 2 * e], v1[8 * i + 2 * e + 1], vh1.u[e], vl1.u[e]);
             }
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, ph.v, o0, 0, 0, 0);
-            if constexpr (!KVBF16) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0.v, ph.v, o0, 0, 0, 0);
-            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, pl.v, o0, 0, 0, 0);
+            if constexpr (!KVBF16) PTTS_LO_MFMA(o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl0.v, ph.v, o0, 0, 0, 0));
+            PTTS_LO_MFMA(o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh0.v, pl.v, o0, 0, 0, 0));
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, ph.v, o1, 0, 0, 0);
-            if constexpr (!KVBF16) o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1.v, ph.v, o1, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, pl.v, o1, 0, 0, 0);
+            if constexpr (!KVBF16) PTTS_LO_MFMA(o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vl1.v, ph.v, o1, 0, 0, 0));
+            PTTS_LO_MFMA(o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vh1.v, pl.v, o1, 0, 0, 0));
         }
     }
     l += __shfl_xor(l, 32, WAVE);

@@ -7,6 +7,15 @@
 
 #include "kernels.h"
 
+// The lo half of every activation split in the DECODER's products (x = hi + lo: two MFMAs per product against bf16 weights).  -DPTTS_ABLATE_LO drops them: the
+// measurement build of tools/probes/hi_only ("what do the f32-grade sums cost on a configuration that says bf16": its time and its error against the oracle are in
+// profiles/r5_hi_only_ablation.txt).  Nothing in the shipped library defines it.
+#ifdef PTTS_ABLATE_LO
+#define PTTS_LO_MFMA(stmt) do { } while (0)
+#else
+#define PTTS_LO_MFMA(stmt) stmt
+#endif
+
 namespace ptts {
 
 #define WAVE 64

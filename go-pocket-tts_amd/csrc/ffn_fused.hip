@@ -168,8 +168,8 @@ __device__ __forceinline__ void ff_gemm1(const char* w1, int r16, int q, const F
         }
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1].v, xh[s].v, acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s & 1].v, xh[s].v, acc[1], 0, 0, 0);
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1].v, xl[s].v, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s & 1].v, xl[s].v, acc[1], 0, 0, 0);
+        PTTS_LO_MFMA(acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[s & 1].v, xl[s].v, acc[0], 0, 0, 0));
+        PTTS_LO_MFMA(acc[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb[s & 1].v, xl[s].v, acc[1], 0, 0, 0));
         piece(s);
         // (both accumulator chains are made to exist HERE: matrix instructions are pure values to the instruction selector, which otherwise lets the
         // second chain float to the end of the block -- behind whatever follows -- before the scheduler's fences ever see it)
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < FF_OT) w2f[(t + 1) & 1].q = *reinterpret_cast<const uint4*>(w2 + (t + 1) * 1024);
             acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t & 1].v, hh.v, acc2[t], 0, 0, 0);
-            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t & 1].v, hl.v, acc2[t], 0, 0, 0);
+            PTTS_LO_MFMA(acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[t & 1].v, hl.v, acc2[t], 0, 0, 0));
             if (t + 1 < FF_OT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             __builtin_amdgcn_sched_barrier(0);

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
                         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, ah[t].v, acc[t][n], 0, 0, 0);
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, al[t].v, acc[t][n], 0, 0, 0);
+                        PTTS_LO_MFMA(acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w.v, al[t].v, acc[t][n], 0, 0, 0));
                     }
                 } else {
                     acc[0][n][0] += __uint_as_float(w.q.x ^ ah[0].q.x ^ al[1].q.y);

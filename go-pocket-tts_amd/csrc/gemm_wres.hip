@@ -135,7 +135,7 @@ __global__ __launch_bounds__(WR_NW * 64) void k_gemm_wres(GemmArgs a, int ntiles
 #pragma unroll
                     for (int t = 0; t < 2; t++) {
                         acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n & 1].v, ah[t].v, acc[t][n], 0, 0, 0);
-                        acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n & 1].v, al[t].v, acc[t][n], 0, 0, 0);
+                        PTTS_LO_MFMA(acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[n & 1].v, al[t].v, acc[t][n], 0, 0, 0));
                     }
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
                 FragR wh;
                 wh.q = w1[(n * KS + s) * 64];
                 acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0);
+                PTTS_LO_MFMA(acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0));
                 if constexpr (!WBF16) {
                     FragR wl;
                     wl.q = w1l[(n * KS + s) * 64];
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
                 FragR wh;
                 wh.q = w2[(n * KS + s) * 64];
                 acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc[n], 0, 0, 0);
-                acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0);
+                PTTS_LO_MFMA(acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0));
                 if constexpr (!WBF16) {
                     FragR wl;
                     wl.q = w2l[(n * KS + s) * 64];
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(NW * 64) void k_resblock(ResArgs a) {
             wh.q = wfh[s * 64];
             wl.q = wfl[s * 64];
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc, 0, 0, 0);
+            PTTS_LO_MFMA(acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc, 0, 0, 0));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc, 0, 0, 0);
         }
         const int gr = row0 + i_lane;                 // result column 0 sits in register 0 of lane group 0

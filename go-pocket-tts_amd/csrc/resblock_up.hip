@@ -176,7 +176,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
 #pragma unroll
                     for (int ct = 0; ct < 2; ct++) {
                         acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[ct][s].v, xh.v, acc[ct][rt], 0, 0, 0);
-                        acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[ct][s].v, xl.v, acc[ct][rt], 0, 0, 0);
+                        PTTS_LO_MFMA(acc[ct][rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wu[ct][s].v, xl.v, acc[ct][rt], 0, 0, 0));
                     }
                 }
             }
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                     FragU wh;
                     wh.q = w1[(n * KS + s) * 64];
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0);
+                    PTTS_LO_MFMA(acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0));
                 }
             }
 #pragma unroll
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                     FragU wh;
                     wh.q = w2[(n * KS + s) * 64];
                     acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc[n], 0, 0, 0);
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0);
+                    PTTS_LO_MFMA(acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc[n], 0, 0, 0));
                 }
             }
 #pragma unroll
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(512) void k_resblock_up(ResArgs a) {
                 wh.q = wfh[s * 64];
                 wl.q = wfl[s * 64];
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xh.v, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc, 0, 0, 0);
+                PTTS_LO_MFMA(acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh.v, xl.v, acc, 0, 0, 0));
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl.v, xh.v, acc, 0, 0, 0);
             }
             const int gr = row0 + i_lane;                 // result column 0 sits in register 0 of lane group 0
