@@ -84,7 +84,9 @@ def _one_process_n_models(pkg, devices):
         assert not any(errs), [str(e) for e in errs if e][:3]
         for i in range(n_clients):
             assert res[i].n_frames == want[i % 16].n_frames
-            np.testing.assert_allclose(res[i].latents, want[i % 16].latents, rtol=0, atol=2e-5 * max(1.0, float(np.abs(want[i % 16].latents).max())))
+            # (a dispatcher batch is whatever arrived together: its packed prefill may take other GEMM tilings than the reference batches of eight did --
+            # kernel-selection rounding over five free-running steps, the tolerance of the other dispatcher tests: tests/test_gpu_model.py)
+            np.testing.assert_allclose(res[i].latents, want[i % 16].latents, rtol=0, atol=1e-4 * max(1.0, float(np.abs(want[i % 16].latents).max())))
         assert st["requests"] == n_clients and st["batches"] >= len(models), st
         base.close()                                       # the replicas own their arenas
         for m in models[1:]:
