@@ -371,9 +371,9 @@ def test_a_cluster_of_long_utterances_ending_together_is_decoded_in_the_step_cha
     prompts = [rng.integers(1, cfg.n_bins, size=5).astype(np.int64) for _ in range(n_long + n_short)]
     steps = [320] * n_long + [int(rng.integers(4, 12)) for _ in range(n_short)]
     cfgs = [pkg.RuntimeGenerateConfig(max_steps=s, eos_threshold=float("inf"), want_latents=True) for s in steps]
-    d = pkg.Dispatcher([gm], max_batch=8, window_us=20_000, continuous=True, cont_kv_capacity=384, cont_max_steps=320, cont_steps_per_group=4)
+    d = pkg.Dispatcher([gm], max_batch=8, window_us=50_000, continuous=True, cont_kv_capacity=384, cont_max_steps=320, cont_steps_per_group=4)
     try:
-        got, errs = run_clients(d, prompts, cfgs)
+        got, errs = run_clients(d, prompts, cfgs, stagger_s=0.001)   # (the queue is first in, first out: the eight long requests take the eight slots together)
         assert not any(errs), errs
     finally:
         d.close()
